@@ -1,0 +1,187 @@
+/*
+ * pb3d.h -- C ABI of libpb3d.so: MI355X (gfx950) semantic voxel carving & re-projection.
+ *
+ * The reference (BarnitaSharma/Part-based-3D-Reconstruction) has no FFI: its boundary for
+ * this path is the Python function surface of utils/voxel_carving_utils.py,
+ * utils/voxel_utils.py, utils/projection_utils.py and utils/camera_estimation.py, called
+ * with NumPy arrays.  This header is what a ctypes binding of those functions binds; each
+ * entry point cites the reference function (file:line) it replaces.  INTEGRATION.md shows
+ * the reference-side stub.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every buffer is caller-owned and C-contiguous;
+ *   - grids are uint8, axes (W=x, H=y, D=z[,3]) in C order, exactly the reference's layout;
+ *   - every function returns 0 on success or a negative PB3D_E* code; pb3d_last_error()
+ *     gives the thread-local message of the last failure;
+ *   - "*_dev" entry points take DEVICE pointers, enqueue on the context's HIP stream and
+ *     return without synchronising (call pb3d_sync); the un-suffixed entry points take
+ *     HOST pointers, stage through device scratch and return when the result is in the
+ *     caller's buffer (these are what the NumPy shim calls);
+ *   - a context belongs to one GPU and one HIP stream; use it from one thread at a time.
+ *   - There is NO CPU fallback: every op fails with PB3D_ENODEVICE when no GPU is present.
+ */
+#ifndef PB3D_H
+#define PB3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pb3d_ctx pb3d_ctx;
+typedef struct pb3d_event pb3d_event;
+
+enum {
+    PB3D_OK = 0,
+    PB3D_EINVAL = -1,       /* bad argument (shape, null pointer, angle ...)           */
+    PB3D_ENODEVICE = -2,    /* no HIP device / HIP runtime error                        */
+    PB3D_ENOMEM = -3,       /* device allocation failed                                  */
+    PB3D_EUNSUPPORTED = -4, /* argument combination outside what the path needs          */
+    PB3D_ECOMM = -5         /* RCCL not available / collective failed                    */
+};
+
+/* ---- lifecycle, device memory, timing (plumbing) ------------------------------------- */
+int pb3d_version(void);
+const char* pb3d_last_error(void);
+int pb3d_device_count(int* n);
+int pb3d_create(int device, pb3d_ctx** out);
+void pb3d_destroy(pb3d_ctx* ctx);
+int pb3d_device_info(pb3d_ctx* ctx, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes);
+int pb3d_sync(pb3d_ctx* ctx);
+int pb3d_dev_alloc(pb3d_ctx* ctx, size_t bytes, void** dptr);
+int pb3d_dev_free(pb3d_ctx* ctx, void* dptr);
+int pb3d_dev_memset(pb3d_ctx* ctx, void* dptr, int value, size_t bytes);
+int pb3d_h2d(pb3d_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
+int pb3d_d2h(pb3d_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
+int pb3d_d2d(pb3d_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* HIP events recorded on the context's stream (the stream every kernel is launched on). */
+int pb3d_event_create(pb3d_ctx* ctx, pb3d_event** ev);
+int pb3d_event_record(pb3d_ctx* ctx, pb3d_event* ev);
+int pb3d_event_elapsed_ms(pb3d_ctx* ctx, pb3d_event* start, pb3d_event* stop, float* ms); /* syncs on stop */
+void pb3d_event_destroy(pb3d_event* ev);
+
+/* ---- host shim H1: pinned rotation data ------------------------------------------------
+ * Rinv(angle) = numpy.linalg.inv of the Y-rotation, reference utils/voxel_carving_utils.py:65-69
+ * (bit patterns pinned for angle = 0..90, see csrc/rotinv_table.inc), and
+ * offset = c - Rinv@c with c = shape/2 as NumPy evaluates it (:108,:119; FMA chain). */
+int pb3d_rotinv(int angle_deg, double M[9]);
+int pb3d_offset(const double M[9], const int64_t shape[3], double off[3]);
+
+/* ---- carve_voxel_grid_with_masks, reference utils/voxel_carving_utils.py:76-87 ----------
+ * out = grid where mask_wh[x,y] != 0 else 0, broadcast over z (and channel).  C = 1 or 3.
+ * mask_wh is the (W,H) uint8 truthiness image, i.e. after _mask_to_wh (:19-28), which is
+ * host logic in the shim.  (The reference's RGB-mask branch :90-95 cannot broadcast for
+ * any non-degenerate shape and always raises; the shim raises the same ValueError.) */
+int pb3d_carve_mask_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t W, int64_t H, int64_t D, int C,
+                        const uint8_t* d_mask_wh, uint8_t* d_out);
+int pb3d_carve_mask(pb3d_ctx* ctx, const uint8_t* grid, int64_t W, int64_t H, int64_t D, int C,
+                    const uint8_t* mask_wh, uint8_t* out);
+
+/* ---- one rotate-about-Y + carve step = scipy.ndimage.affine_transform(order=1,
+ * mode="constant", cval=0) followed by the mask carve; call site
+ * reference utils/voxel_carving_utils.py:116-124.  M must have row 1 == [+-0, 1, +-0]
+ * and off[1] == 0 (true for every Rinv).  d_mask_wh may be NULL (no carve). */
+int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
+                          const double M[9], const double off[3], const uint8_t* d_mask_wh, uint8_t* d_out);
+int pb3d_rotate_carve(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, int64_t D,
+                      const double M[9], const double off[3], const uint8_t* mask_wh, uint8_t* out);
+
+/* ---- process_voxel_grid, reference utils/voxel_carving_utils.py:104-126 ------------------
+ * for angle in range(0, 91, angle_interval): rotate-carve; cumulative.  The loop runs on
+ * the device.  d_tmp: W*H*D bytes of scratch (ping-pong); d_out may not alias d_occ. */
+int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
+                          const uint8_t* d_mask_wh, int angle_interval, uint8_t* d_out, uint8_t* d_tmp);
+int pb3d_process_grid(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, int64_t D,
+                      const uint8_t* mask_wh, int angle_interval, uint8_t* out);
+
+/* ---- _occupancy, reference utils/voxel_carving_utils.py:32-33: any(grid > 0, axis=-1) ---- */
+int pb3d_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t nvox, uint8_t* d_occ);
+int pb3d_occupancy(pb3d_ctx* ctx, const uint8_t* grid_rgb, int64_t nvox, uint8_t* occ);
+
+/* ---- apply_colored_mask_to_voxel_grid, reference utils/voxel_carving_utils.py:128-136 ----
+ * out[x,y,z,:] = rgb_hw3[y,x,:] where carved[x,y,z] == 1 else 0. */
+int pb3d_color_apply_dev(pb3d_ctx* ctx, const uint8_t* d_carved, int64_t W, int64_t H, int64_t D,
+                         const uint8_t* d_rgb_hw3, uint8_t* d_out);
+int pb3d_color_apply(pb3d_ctx* ctx, const uint8_t* carved, int64_t W, int64_t H, int64_t D,
+                     const uint8_t* rgb_hw3, uint8_t* out);
+
+/* ---- global_carve, reference utils/voxel_carving_utils.py:269-298 -------------------------
+ * ones((w,h,w)) -> process_voxel_grid -> colour.  bin_hw: (h,w) truthiness uint8,
+ * rgb_hw3: (h,w,3).  out: (w,h,w,3).  The x-range [x0,x1) variant computes only that slab
+ * of the output (slab pointer = start of the slab), for sharded runs. */
+int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t* d_rgb_hw3, int64_t h, int64_t w,
+                          int angle_interval, int64_t x0, int64_t x1, uint8_t* d_out_slab);
+int pb3d_global_carve(pb3d_ctx* ctx, const uint8_t* bin_hw, const uint8_t* rgb_hw3, int64_t h, int64_t w,
+                      int angle_interval, uint8_t* out);
+
+/* ---- part_carve, reference utils/voxel_carving_utils.py:139-160 ---------------------------
+ * Job j is described by two (W,H) uint8 0/1 images (the shim derives them from the
+ * semantic mask, :143-151): mask_sub[j] = mask2d.T gates `sub`; mask_carve[j] =
+ * _mask_to_wh(mask2d.T) is what process_voxel_grid uses (differs only when W == H).
+ * job_skip[j] != 0 marks jobs whose mask2d is empty (:148).  out is zero where no job keeps. */
+int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int64_t H, int64_t D,
+                        const uint8_t* d_mask_sub, const uint8_t* d_mask_carve, const int* job_angle,
+                        const int* job_skip, int njobs, uint8_t* d_out);
+int pb3d_part_carve(pb3d_ctx* ctx, const uint8_t* colored, int64_t W, int64_t H, int64_t D,
+                    const uint8_t* mask_sub, const uint8_t* mask_carve, const int* job_angle,
+                    const int* job_skip, int njobs, uint8_t* out);
+
+/* ---- grid -> points: get_voxel_points_by_parts (reference utils/voxel_utils.py:7-21) and
+ * voxel_grid_to_points (:35-51).  Grid (A0,A1,A2[,C]); a voxel on the stride lattice is
+ * selected if its RGB equals one of colors[ncolors][3] (ncolors > 0, C == 3) or if any of
+ * its C channels is non-zero (ncolors == 0).  Points come out in numpy.where order as
+ * float32 (a2,a1,a0)*stride plus the voxel's C bytes.  count first, then fill with
+ * buffers of exactly n rows. */
+int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C,
+                          const uint8_t* colors, int ncolors, int stride, int64_t* n);
+int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C,
+                         const uint8_t* colors, int ncolors, int stride, int64_t n, float* d_pts, uint8_t* d_cols);
+int pb3d_points_count(pb3d_ctx* ctx, const uint8_t* grid, int64_t A0, int64_t A1, int64_t A2, int C,
+                      const uint8_t* colors, int ncolors, int stride, int64_t* n);
+int pb3d_points_fill(pb3d_ctx* ctx, int64_t n, float* pts, uint8_t* cols); /* after pb3d_points_count on the same ctx */
+
+/* ---- project_colored_voxels, reference utils/projection_utils.py:5-23 ---------------------
+ * R = look_at_rotation(cam, target) (host, reference utils/camera_geometry.py:3-14) is
+ * passed in.  pts: (n,3) float32 (pts_f64 = 0) or float64 (1); cols (n,3) uint8.
+ * prec[4] = arithmetic width (0 = float32, 1 = float64) of {matmul+divide, *f, +cx, +cy}
+ * as NumPy-2 promotion decides it from the caller's types.  img (Himg,Wimg,3) is fully
+ * written; among points landing on one pixel the last in input order wins. */
+int pb3d_project_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_t* d_cols, int64_t n,
+                     const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4],
+                     int Himg, int Wimg, uint8_t* d_img);
+int pb3d_project(pb3d_ctx* ctx, const void* pts, int pts_f64, const uint8_t* cols, int64_t n,
+                 const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4],
+                 int Himg, int Wimg, uint8_t* img);
+
+/* ---- compute_partwise_iou, reference utils/camera_estimation.py:770-787 -------------------
+ * per colour k: inter[k] = #(a==c & b==c), uni[k] = #(a==c | b==c) over npix RGB pixels. */
+int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64_t npix,
+                          const uint8_t* colors, int ncolors, int64_t* inter, int64_t* uni);
+int pb3d_partwise_iou(pb3d_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t npix,
+                      const uint8_t* colors, int ncolors, int64_t* inter, int64_t* uni);
+
+/* ---- seeded synthetic inputs generated on the device ---------------------
+ * mask16: labels (S,S) uint8 in 0..15 by the closed formula scaled from S=1024; binary and
+ * rgb derive from it.  Any output pointer may be NULL.  sem grid: palette[label16 of a
+ * splitmix64 hash of the voxel index] (kind 0) -- worst case for any sparsity trick. */
+int pb3d_synth_mask16_dev(pb3d_ctx* ctx, int64_t S, uint8_t* d_label_hw, uint8_t* d_binary_hw, uint8_t* d_rgb_hw3,
+                          uint8_t* d_binary_wh);
+int pb3d_synth_sem_dev(pb3d_ctx* ctx, int64_t x0, int64_t x1, int64_t H, int64_t D, uint64_t seed, uint8_t* d_slab_rgb);
+int pb3d_synth_occ_dev(pb3d_ctx* ctx, int64_t x0, int64_t x1, int64_t H, int64_t D, uint64_t seed, uint8_t* d_slab);
+int pb3d_synth_palette16(uint8_t palette[48]);
+
+/* ---- multi-GPU: slab reassembly with ONE RCCL all-gather over xGMI -----------------------
+ * One process per GPU.  Rank 0 obtains a 128-byte id, the launcher distributes it, every
+ * rank calls pb3d_comm_init.  pb3d_allgather_dev gathers `bytes_per_rank` from each rank's
+ * d_send into d_recv[rank * bytes_per_rank ...] (d_send may be the rank's own slot: in place). */
+int pb3d_comm_unique_id(uint8_t id[128]);
+int pb3d_comm_init(pb3d_ctx* ctx, const uint8_t id[128], int rank, int nranks);
+int pb3d_allgather_dev(pb3d_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+int pb3d_comm_destroy(pb3d_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PB3D_H */

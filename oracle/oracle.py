@@ -1,0 +1,307 @@
+"""CPU ORACLE -- NumPy-signature front end of oracle/libpb3d_oracle.so.
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.  Function names and
+argument meaning follow the reference's L2 surface so parity tests read like calls into
+the reference:
+
+    reference utils/voxel_carving_utils.py : carve_voxel_grid_with_masks (:76),
+        process_voxel_grid (:104), apply_colored_mask_to_voxel_grid (:128),
+        part_carve (:139), global_carve (:269), _occupancy (:32), _mask_to_wh (:19)
+    reference utils/voxel_utils.py         : get_voxel_points_by_parts (:7),
+        voxel_grid_to_points (:35)
+    reference utils/camera_geometry.py     : look_at_rotation (:3)
+    reference utils/projection_utils.py    : project_colored_voxels (:5)
+    reference utils/camera_estimation.py   : compute_partwise_iou (:770)
+
+Parity pin: tests/test_oracle_golden.py checks every function below against vectors
+captured from the imported reference (tools/gen_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PART_COLORS = {  # reference utils/config.py:29-40 (palette values are data the path keys on)
+    "full_building": (253, 248, 96), "chhatris": (1, 220, 5), "plinth": (63, 138, 173),
+    "dome": (190, 0, 255), "front_minarets": (0, 0, 255), "back_minarets": (5, 223, 223),
+    "small_minarets": (255, 180, 80), "main_door": (180, 140, 255), "windows": (255, 120, 230),
+    "background": (216, 224, 251),
+}
+
+_u8p = C.POINTER(C.c_uint8)
+_i64 = C.c_int64
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpb3d_oracle.so")
+    src = os.path.join(_HERE, "pb3d_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_points.restype = _i64
+    return _LIB
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
+
+
+def _p(a, t=_u8p):
+    return a.ctypes.data_as(t)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u8c(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8:
+        raise TypeError("oracle handles uint8 grids only, got %s" % a.dtype)
+    return a
+
+
+def _truth(a):
+    return np.ascontiguousarray(np.asarray(a) != 0).view(np.uint8)
+
+
+def mask_to_wh(mask, W, H):
+    """_mask_to_wh, voxel_carving_utils.py:19-28: the (H,W) test is made first."""
+    mask = np.asarray(mask)
+    if mask.shape[:2] == (H, W):
+        return mask.T
+    if mask.shape[:2] == (W, H):
+        return mask
+    raise ValueError(f"Mask shape {mask.shape} incompatible with (W,H)=({W},{H})")
+
+
+def rotation_matrix_inv(angle):
+    M = np.empty(9, np.float64)
+    if lib().orc_rotinv(int(angle), _dp(M)) != 0:
+        raise ValueError("angle outside 0..90")
+    return M.reshape(3, 3)
+
+
+def affine_offset(M, shape):
+    M = np.ascontiguousarray(M, np.float64)
+    sh = (_i64 * 3)(*[int(s) for s in shape])
+    off = np.empty(3, np.float64)
+    lib().orc_offset(_dp(M), sh, _dp(off))
+    return off
+
+
+def affine_transform_u8(grid, M, off):
+    g = _u8c(grid)
+    W, H, D = g.shape
+    out = np.empty_like(g)
+    M = np.ascontiguousarray(M, np.float64)
+    off = np.ascontiguousarray(off, np.float64)
+    lib().orc_affine_u8(_p(g), _i64(W), _i64(H), _i64(D), _dp(M), _dp(off), _p(out))
+    return out
+
+
+def occupancy(grid):
+    g = _u8c(grid)
+    out = np.empty(g.shape[:3], np.uint8)
+    lib().orc_occupancy(_p(g), _i64(out.size), _p(out))
+    return out
+
+
+def carve_voxel_grid_with_masks(voxel_grid, combined_mask):
+    g = _u8c(voxel_grid)
+    W, H, D = g.shape[:3]
+    Cc = 3 if g.ndim == 4 else 1
+    if g.ndim == 4 and g.shape[3] != 3:
+        raise ValueError("colour grids must have 3 channels")
+    m = mask_to_wh(combined_mask, W, H)
+    if m.ndim == 2:
+        mc = 1
+    elif m.ndim == 3 and m.shape[2] == 3:
+        # reference :90-95 broadcasts a (W,H,1,1) selector against a (W,H,D) channel slab,
+        # which NumPy rejects for every non-degenerate shape -> the call ends in ValueError.
+        raise ValueError("operands could not be broadcast together (RGB mask branch)")
+    else:
+        raise ValueError("Unsupported mask shape")
+    mt = _truth(m)
+    out = np.empty_like(g)
+    rc = lib().orc_carve_mask(_p(g), _i64(W), _i64(H), _i64(D), Cc, _p(mt), mc, _p(out))
+    assert rc == 0
+    return out
+
+
+def process_voxel_grid(voxel_grid, combined_mask, angle_interval=90):
+    g = _u8c(voxel_grid)
+    W, H, D = g.shape
+    m = mask_to_wh(combined_mask, W, H)
+    if m.ndim != 2:
+        raise ValueError("oracle: process_voxel_grid takes a binary 2-D mask")
+    mt = _truth(m)
+    out = np.empty_like(g)
+    rc = lib().orc_process_grid(_p(g), _i64(W), _i64(H), _i64(D), _p(mt), int(angle_interval), _p(out))
+    if rc != 0:
+        raise ValueError("angle_interval must be a positive integer")
+    return out
+
+
+def apply_colored_mask_to_voxel_grid(carved_voxel_grid, colored_mask):
+    cv = _u8c(carved_voxel_grid)
+    W, H, D = cv.shape
+    rgb = _u8c(colored_mask)
+    assert rgb.shape == (H, W, 3)
+    out = np.empty((W, H, D, 3), np.uint8)
+    lib().orc_color_apply(_p(cv), _i64(W), _i64(H), _i64(D), _p(rgb), _p(out))
+    return out
+
+
+def global_carve(binary_mask, semantic_mask_exterior, angle_interval=90, stride=4, visualize=False):
+    b = _truth(binary_mask)
+    h, w = b.shape
+    rgb = _u8c(semantic_mask_exterior)
+    assert rgb.shape == (h, w, 3)
+    out = np.empty((w, h, w, 3), np.uint8)
+    rc = lib().orc_global_carve(_p(b), _p(rgb), _i64(h), _i64(w), int(angle_interval), _p(out))
+    if rc != 0:
+        raise ValueError("angle_interval must be a positive integer")
+    return out
+
+
+def part_masks(semantic_mask, names, part_colors=PART_COLORS):
+    """mask2d of voxel_carving_utils.py:143-146, (H,W) bool."""
+    sm = np.asarray(semantic_mask)
+    m = np.zeros(sm.shape[:2], bool)
+    for n in names:
+        c = np.asarray(part_colors[n])
+        m |= (sm[..., 0] == c[0]) & (sm[..., 1] == c[1]) & (sm[..., 2] == c[2])
+    return m
+
+
+def part_carve(colored_grid, semantic_mask, group_jobs, visualize=False, part_colors=PART_COLORS):
+    g = _u8c(colored_grid)
+    W, H, D, _ = g.shape
+    nj = len(group_jobs)
+    msub = np.zeros((max(nj, 1), W, H), np.uint8)
+    mcarve = np.zeros((max(nj, 1), W, H), np.uint8)
+    ang = (C.c_int * max(nj, 1))()
+    skip = (C.c_int * max(nj, 1))()
+    for j, (names, angle) in enumerate(group_jobs):
+        m2 = part_masks(semantic_mask, names, part_colors)
+        skip[j] = 0 if m2.any() else 1
+        ang[j] = int(angle)
+        m = m2.T.astype(np.uint8)
+        msub[j] = m
+        mcarve[j] = np.ascontiguousarray(mask_to_wh(m, W, H))
+    out = np.empty_like(g)
+    rc = lib().orc_part_carve(_p(g), _i64(W), _i64(H), _i64(D), _p(msub), _p(mcarve), ang, skip, nj, _p(out))
+    if rc != 0:
+        raise ValueError("part_carve failed rc=%d" % rc)
+    return out
+
+
+def _points(grid, colors, stride):
+    g = _u8c(grid)
+    A0, A1, A2 = g.shape[:3]
+    Cc = g.shape[3] if g.ndim == 4 else 1
+    cols = np.ascontiguousarray(np.asarray(colors, np.uint8).reshape(-1, 3)) if colors is not None else np.zeros((0, 3), np.uint8)
+    args = (_p(g), _i64(A0), _i64(A1), _i64(A2), Cc, _p(cols) if len(cols) else None, len(cols), int(stride))
+    n = lib().orc_points(*args, None, None)
+    pts = np.empty((n, 3), np.float32)
+    pc = np.empty((n, Cc), np.uint8)
+    lib().orc_points(*args, pts.ctypes.data_as(C.POINTER(C.c_float)), _p(pc))
+    return pts, pc
+
+
+def get_voxel_points_by_parts(grid, part_colors, part_names):
+    cols = [part_colors[n] for n in part_names]
+    if not cols:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8)
+    return _points(grid, cols, 1)
+
+
+def voxel_grid_to_points(grid, axis="z", colormap="viridis", stride=2):
+    grid = np.asarray(grid)
+    W, H, D = grid.shape[:3]
+    is_color = grid.ndim == 4 and grid.shape[3] == 3
+    pts, pc = _points(grid, None, stride)
+    if not is_color:
+        raise NotImplementedError("oracle: colormap branch is visualisation-only (matplotlib)")
+    return pts, pc, (H, W, D)
+
+
+def look_at_rotation(eye, target, up=None):
+    """camera_geometry.py:3-14, NumPy operations in the same order and dtypes."""
+    if up is None:
+        up = np.array([0, 1, 0], dtype=np.float32)
+    z = target - eye
+    z = z / np.linalg.norm(z)
+    if np.allclose(np.abs(np.dot(z, up)), 1.0):
+        up = np.array([0, 0, 1], dtype=np.float32)
+    x = np.cross(up, z)
+    x = x / np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.stack([x, y, z], axis=0)
+
+
+def _is_f64_scalar(v):
+    """NumPy-2 (NEP 50) promotion: Python floats/ints are weak; NumPy scalars/arrays carry a dtype."""
+    if isinstance(v, (np.generic, np.ndarray)):
+        return np.result_type(v, np.float32) == np.float64
+    return False
+
+
+def project_colored_voxels(pts3d, colors, cam_pos, target, f, cx, cy, H, W):
+    pts3d = np.asarray(pts3d)
+    cam_pos = np.asarray(cam_pos)
+    target = np.asarray(target)
+    R = look_at_rotation(cam_pos, target)
+    t0 = int(np.result_type(pts3d, cam_pos, R) == np.float64)
+    tm = int(t0 or _is_f64_scalar(f))
+    tu = int(tm or _is_f64_scalar(cx))
+    tv = int(tm or _is_f64_scalar(cy))
+    prec = (C.c_int * 4)(t0, tm, tu, tv)
+    if pts3d.dtype == np.float64:
+        p = np.ascontiguousarray(pts3d, np.float64); pf64 = 1
+    else:
+        p = np.ascontiguousarray(pts3d, np.float32); pf64 = 0
+    cols = np.ascontiguousarray(colors, np.uint8)
+    n = p.shape[0]
+    Rd = np.ascontiguousarray(R, np.float64)
+    cd = np.ascontiguousarray(cam_pos, np.float64)
+    img = np.empty((H, W, 3), np.uint8)
+    lib().orc_project(p.ctypes.data_as(C.c_void_p), pf64, _p(cols), _i64(n), _dp(Rd), _dp(cd),
+                      C.c_double(float(f)), C.c_double(float(cx)), C.c_double(float(cy)), prec,
+                      int(H), int(W), _p(img))
+    return img
+
+
+def partwise_iou_counts(projected_img, image, colors):
+    a = _u8c(projected_img); b = _u8c(image)
+    cols = np.ascontiguousarray(np.asarray(colors, np.uint8).reshape(-1, 3))
+    inter = np.zeros(len(cols), np.int64); uni = np.zeros(len(cols), np.int64)
+    lib().orc_partwise_iou(_p(a), _p(b), _i64(a.size // 3), _p(cols), len(cols),
+                           inter.ctypes.data_as(C.POINTER(_i64)), uni.ctypes.data_as(C.POINTER(_i64)))
+    return inter, uni
+
+
+def compute_partwise_iou(proj_mask, gt_mask, part_colors):
+    """camera_estimation.py:770-787: ({part: inter/union or 0.0}, mean)."""
+    names = list(part_colors.keys())
+    inter, uni = partwise_iou_counts(proj_mask, gt_mask, [part_colors[n] for n in names])
+    per = {}
+    for n, i, u in zip(names, inter, uni):
+        per[n] = (i / u) if u > 0 else 0.0
+    return per, np.mean(list(per.values()))

@@ -1,0 +1,326 @@
+// K1 mask-carve sweep, occupancy, colour apply, part overlay -- HBM-bound byte kernels (gfx950).
+//
+// Data layout (the reference's own): grid (W,H,D[,3]) uint8 in C order, so the D*C bytes of
+// one (x,y) column are contiguous and column index xy = x*H + y also indexes the (W,H) mask.
+// Every kernel here is a coalesced 16-byte-per-lane sweep; none has a contraction (no MFMA).
+#include "pb3d_internal.h"
+
+namespace {
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+
+// ------------------------------------------------------------------------------------------------
+// K1 fast path: column size col = D*C is a multiple of 16 bytes, buffers 16-byte aligned.
+// One wavefront owns a tile of 64 consecutive columns: lane l reads mask byte l of the tile,
+// a wave64 ballot turns the 64 keep/drop decisions into one 64-bit scalar word, and the wave
+// then sweeps the tile's 64*vpc 16-byte vectors.  Dropped columns are never read -- their
+// lanes are predicated off (wave-uniformly when vpc % 64 == 0) and only zeros are stored.
+// ------------------------------------------------------------------------------------------------
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_carve_cols(const u32x4* __restrict__ in, u32x4* __restrict__ out,
+                                                    const u8* __restrict__ mask, i64 ncols, u32 vpc, u32 magic,
+                                                    i64 ntiles) {
+    const u32 lane = threadIdx.x & 63;
+    // wave index made provably wave-uniform so tile bounds and the keep test live in SGPRs
+    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);
+    for (i64 t = wave; t < ntiles; t += nwaves) {
+        const i64 col0 = t * 64;
+        const i64 c_here = ncols - col0 < 64 ? ncols - col0 : 64;
+        const u8 m = (i64)lane < c_here ? mask[col0 + lane] : (u8)0;
+        const u64 kbits = __ballot(m != 0);
+        const u32 nvec = (u32)c_here * vpc;
+        const u32x4* src = in + col0 * vpc;
+        u32x4* dst = out + col0 * vpc;
+        for (u32 v0 = 0; v0 < nvec; v0 += 256) {
+            u32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32 vv = v0 + 64 * u + lane;
+                x[u] = (u32x4)(0u);
+                if (UNIFORM) {
+                    // vpc % 64 == 0: the 64 lanes of this step sit in one column -> scalar decision
+                    const u32 vs = v0 + 64 * u;
+                    if (vs < nvec) {
+                        const u32 c = __umulhi(vs, magic);
+                        if ((kbits >> c) & 1) x[u] = ld_nt(src + vv);
+                    }
+                } else {
+                    if (vv < nvec) {
+                        const u32 c = magic ? __umulhi(vv, magic) : vv / vpc;
+                        if ((kbits >> c) & 1) x[u] = ld_nt(src + vv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32 vv = v0 + 64 * u + lane;
+                if (vv < nvec) st_nt(dst + vv, x[u]);
+            }
+        }
+    }
+}
+
+// K1 generic path: any column size / alignment; one thread per byte run of 16 (slow, rarely used:
+// only when D*C is not a multiple of 16 or a slab pointer is unaligned).
+__global__ __launch_bounds__(256) void k_carve_bytes(const u8* __restrict__ in, u8* __restrict__ out,
+                                                     const u8* __restrict__ mask, i64 nbytes, i64 col) {
+    const i64 nchunks = (nbytes + 15) / 16;
+    for (i64 ch = (i64)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (i64)gridDim.x * blockDim.x) {
+        i64 b = ch * 16;
+        const i64 e = b + 16 < nbytes ? b + 16 : nbytes;
+        i64 c = b / col;
+        i64 rem = b - c * col;
+        u8 keep = mask[c];
+        for (; b < e; ++b) {
+            if (rem == col) {
+                rem = 0;
+                ++c;
+                keep = mask[c];
+            }
+            out[b] = keep ? in[b] : (u8)0;
+            ++rem;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// _occupancy: 16 voxels (48 bytes in, 16 bytes out) per thread.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 byte_of(const u32* w, int idx) { return (w[idx >> 2] >> ((idx & 3) * 8)) & 0xffu; }
+
+__global__ __launch_bounds__(256) void k_occupancy16(const u32x4* __restrict__ rgb, u32x4* __restrict__ occ, i64 ngroups) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        u32 w[12];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const u32x4 v = ld_nt(rgb + 3 * g + k);
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+        u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const u32 any = byte_of(w, 3 * i) | byte_of(w, 3 * i + 1) | byte_of(w, 3 * i + 2);
+            o[i >> 2] |= (any ? 1u : 0u) << ((i & 3) * 8);
+        }
+        u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+        st_nt(occ + g, r);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_occupancy_tail(const u8* __restrict__ rgb, u8* __restrict__ occ, i64 v0, i64 nvox) {
+    for (i64 v = v0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x)
+        occ[v] = (rgb[3 * v] | rgb[3 * v + 1] | rgb[3 * v + 2]) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply_colored_mask_to_voxel_grid: out[x,y,z,:] = rgb[y,x,:] if carved[x,y,z] == 1 else 0.
+// Fast path (D % 16 == 0): 16 voxels of one column per thread -> 16 bytes in, 48 bytes out.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void expand16(const u32 keep16, const u32 r, const u32 g, const u32 b, u32 w[12]) {
+    // byte j of the 48 output bytes belongs to voxel j/3 and channel j%3
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        u32 word = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = 4 * k + q;
+            const int vox = j / 3, ch = j % 3;
+            const u32 val = ch == 0 ? r : (ch == 1 ? g : b);
+            word |= (((keep16 >> vox) & 1u) ? val : 0u) << (8 * q);
+        }
+        w[k] = word;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_color_apply16(const u32x4* __restrict__ carved, const u8* __restrict__ rgb_hw3,
+                                                       u32x4* __restrict__ out, i64 W, i64 H, i64 D16, i64 ngroups) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        const i64 xy = g / D16;
+        const i64 x = xy / H, y = xy - x * H;
+        const u8* px = rgb_hw3 + (y * W + x) * 3;
+        const u32x4 cv = ld_nt(carved + g);
+        const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        u32 keep16 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep16 |= (byte_of(cw, i) == 1u ? 1u : 0u) << i;
+        u32 w[12];
+        expand16(keep16, px[0], px[1], px[2], w);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32x4 r; r.x = w[4 * k]; r.y = w[4 * k + 1]; r.z = w[4 * k + 2]; r.w = w[4 * k + 3];
+            st_nt(out + 3 * g + k, r);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_color_apply_generic(const u8* __restrict__ carved, const u8* __restrict__ rgb_hw3,
+                                                             u8* __restrict__ out, i64 W, i64 H, i64 D) {
+    const i64 nvox = W * H * D;
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+        const i64 xy = v / D;
+        const i64 x = xy / H, y = xy - x * H;
+        const u8* px = rgb_hw3 + (y * W + x) * 3;
+        const bool on = carved[v] == 1;
+        out[3 * v] = on ? px[0] : (u8)0;
+        out[3 * v + 1] = on ? px[1] : (u8)0;
+        out[3 * v + 2] = on ? px[2] : (u8)0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// part_carve helpers.
+//   k_part_occ   : occ[v] = mask_sub[xy] && any(colored[v] > 0)            (reference :152-154)
+//   k_keep_or    : keep[v] |= carved[v] && mask_sub[xy]                    (part = sub * carved, :156)
+//   k_part_final : out[v] = keep[v] ? colored[v] : 0                       (:158; every job writes
+//                  colored[v] itself, so the overlay is the union of the jobs' keep sets)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_part_occ(const u8* __restrict__ colored, const u8* __restrict__ mask_sub,
+                                                  u8* __restrict__ occ, i64 nvox, i64 D) {
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+        const i64 xy = v / D;
+        u8 r = 0;
+        if (mask_sub[xy]) r = (colored[3 * v] | colored[3 * v + 1] | colored[3 * v + 2]) ? 1 : 0;
+        occ[v] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_keep_or(const u8* __restrict__ carved, const u8* __restrict__ mask_sub,
+                                                 u8* __restrict__ keep, i64 nvox, i64 D, int first) {
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+        const i64 xy = v / D;
+        // part = (colored*m)*carved in uint8: non-zero iff m, carved (0/1 here) and colour non-zero
+        const u8 k = (mask_sub[xy] && carved[v]) ? 1 : 0;
+        keep[v] = first ? k : (u8)(keep[v] | k);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_part_final(const u8* __restrict__ colored, const u8* __restrict__ keep,
+                                                    u8* __restrict__ out, i64 nvox) {
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+        const bool k = keep[v] != 0;
+        out[3 * v] = k ? colored[3 * v] : (u8)0;
+        out[3 * v + 1] = k ? colored[3 * v + 1] : (u8)0;
+        out[3 * v + 2] = k ? colored[3 * v + 2] : (u8)0;
+    }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int pb3d_carve_mask_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t W, int64_t H, int64_t D, int C,
+                        const uint8_t* d_mask_wh, uint8_t* d_out) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_carve_mask: null context");
+    PB3D_REQUIRE(W >= 0 && H >= 0 && D >= 0 && (C == 1 || C == 3), "pb3d_carve_mask: bad shape (%lld,%lld,%lld,%d)",
+                 (long long)W, (long long)H, (long long)D, C);
+    const i64 ncols = W * H, col = D * C, nbytes = ncols * col;
+    if (nbytes == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid && d_mask_wh && d_out, "pb3d_carve_mask: null buffer");
+    PB3D_REQUIRE(d_grid != d_out, "pb3d_carve_mask: in-place carve is not supported");
+    const bool fast = (col % 16 == 0) && aligned16(d_grid) && aligned16(d_out) && (col / 16) < (1u << 25);
+    if (fast) {
+        const u32 vpc = (u32)(col / 16);
+        // c = vv / vpc for vv < 64*vpc through one umulhi: exact while 64*vpc*vpc < 2^32
+        u32 magic = 0;
+        if (vpc == 1) magic = 0;  // handled by the division path (vv / 1)
+        else if ((u64)64 * vpc * vpc < (1ull << 32)) magic = (u32)(((1ull << 32) + vpc - 1) / vpc);
+        const i64 ntiles = (ncols + 63) / 64;
+        const unsigned blocks = pb3d_stream_blocks(ctx, ntiles, 4, 8);
+        const bool uniform = (vpc % 64 == 0) && magic != 0;
+        if (uniform)
+            hipLaunchKernelGGL(k_carve_cols<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)d_grid,
+                               (u32x4*)d_out, d_mask_wh, ncols, vpc, magic, ntiles);
+        else
+            hipLaunchKernelGGL(k_carve_cols<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)d_grid,
+                               (u32x4*)d_out, d_mask_wh, ncols, vpc, magic, ntiles);
+    } else {
+        const unsigned blocks = pb3d_stream_blocks(ctx, (nbytes + 15) / 16, 256, 8);
+        hipLaunchKernelGGL(k_carve_bytes, dim3(blocks), dim3(256), 0, ctx->stream, d_grid, d_out, d_mask_wh, nbytes, col);
+    }
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+int pb3d_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t nvox, uint8_t* d_occ) {
+    PB3D_REQUIRE(ctx != nullptr && nvox >= 0, "pb3d_occupancy: bad argument");
+    if (nvox == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid_rgb && d_occ, "pb3d_occupancy: null buffer");
+    i64 done = 0;
+    if (aligned16(d_grid_rgb) && aligned16(d_occ) && nvox >= 16) {
+        const i64 ngroups = nvox / 16;
+        hipLaunchKernelGGL(k_occupancy16, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 8)), dim3(256), 0, ctx->stream,
+                           (const u32x4*)d_grid_rgb, (u32x4*)d_occ, ngroups);
+        PB3D_CHECK_LAUNCH();
+        done = ngroups * 16;
+    }
+    if (done < nvox) {
+        hipLaunchKernelGGL(k_occupancy_tail, dim3(pb3d_stream_blocks(ctx, nvox - done, 256, 8)), dim3(256), 0, ctx->stream,
+                           d_grid_rgb, d_occ, done, nvox);
+        PB3D_CHECK_LAUNCH();
+    }
+    return PB3D_OK;
+}
+
+int pb3d_color_apply_dev(pb3d_ctx* ctx, const uint8_t* d_carved, int64_t W, int64_t H, int64_t D,
+                         const uint8_t* d_rgb_hw3, uint8_t* d_out) {
+    PB3D_REQUIRE(ctx != nullptr && W >= 0 && H >= 0 && D >= 0, "pb3d_color_apply: bad shape");
+    const i64 nvox = W * H * D;
+    if (nvox == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_carved && d_rgb_hw3 && d_out, "pb3d_color_apply: null buffer");
+    if (D % 16 == 0 && aligned16(d_carved) && aligned16(d_out)) {
+        const i64 ngroups = nvox / 16;
+        hipLaunchKernelGGL(k_color_apply16, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 8)), dim3(256), 0, ctx->stream,
+                           (const u32x4*)d_carved, d_rgb_hw3, (u32x4*)d_out, W, H, D / 16, ngroups);
+    } else {
+        hipLaunchKernelGGL(k_color_apply_generic, dim3(pb3d_stream_blocks(ctx, nvox, 256, 8)), dim3(256), 0, ctx->stream,
+                           d_carved, d_rgb_hw3, d_out, W, H, D);
+    }
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int64_t H, int64_t D,
+                        const uint8_t* d_mask_sub, const uint8_t* d_mask_carve, const int* job_angle,
+                        const int* job_skip, int njobs, uint8_t* d_out) {
+    PB3D_REQUIRE(ctx != nullptr && W >= 0 && H >= 0 && D >= 0 && njobs >= 0, "pb3d_part_carve: bad shape");
+    const i64 nvox = W * H * D;
+    if (nvox == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_colored && d_out && (njobs == 0 || (d_mask_sub && d_mask_carve && job_angle && job_skip)),
+                 "pb3d_part_carve: null buffer");
+    for (int j = 0; j < njobs; ++j)
+        PB3D_REQUIRE(job_skip[j] || job_angle[j] > 0, "pb3d_part_carve: job %d has angle %d (must be > 0)", j, job_angle[j]);
+    void *occ, *carved, *tmp, *keep;
+    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &occ));
+    PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));
+    PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
+    PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)nvox, &keep));
+    const unsigned blocks = pb3d_stream_blocks(ctx, nvox, 256, 8);
+    bool any = false;
+    for (int j = 0; j < njobs; ++j) {
+        if (job_skip[j]) continue;
+        const u8* ms = d_mask_sub + (i64)j * W * H;
+        const u8* mc = d_mask_carve + (i64)j * W * H;
+        hipLaunchKernelGGL(k_part_occ, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D);
+        PB3D_CHECK_LAUNCH();
+        PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
+        hipLaunchKernelGGL(k_keep_or, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D,
+                           any ? 0 : 1);
+        PB3D_CHECK_LAUNCH();
+        any = true;
+    }
+    if (!any) {
+        PB3D_HIP(hipMemsetAsync(d_out, 0, (size_t)nvox * 3, ctx->stream));
+        return PB3D_OK;
+    }
+    hipLaunchKernelGGL(k_part_final, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+// Context, device memory, events, error strings and the pinned rotation data (host shim H1).
+#include <cmath>
+#include <cstdlib>
+
+#include "pb3d_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void pb3d_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int pb3d_version(void) { return 100; }
+
+const char* pb3d_last_error(void) { return g_err; }
+
+int pb3d_device_count(int* n) {
+    PB3D_REQUIRE(n != nullptr, "pb3d_device_count: null output");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return PB3D_OK;
+}
+
+int pb3d_create(int device, pb3d_ctx** out) {
+    PB3D_REQUIRE(out != nullptr, "pb3d_create: null output");
+    *out = nullptr;
+    int n = 0;
+    pb3d_device_count(&n);
+    if (n <= 0) {
+        pb3d_set_error("pb3d_create: no HIP device visible (libpb3d has no CPU fallback)");
+        return PB3D_ENODEVICE;
+    }
+    PB3D_REQUIRE(device >= 0 && device < n, "pb3d_create: device %d out of range (have %d)", device, n);
+    PB3D_HIP(hipSetDevice(device));
+    pb3d_ctx* ctx = (pb3d_ctx*)calloc(1, sizeof(pb3d_ctx));
+    if (!ctx) {
+        pb3d_set_error("pb3d_create: out of host memory");
+        return PB3D_ENOMEM;
+    }
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        free(ctx);
+        pb3d_set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        return PB3D_ENODEVICE;
+    }
+    ctx->cus = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        free(ctx);
+        pb3d_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        return PB3D_ENODEVICE;
+    }
+    ctx->pinned_bytes = 1 << 16;
+    e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        free(ctx);
+        pb3d_set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+        return PB3D_ENOMEM;
+    }
+    *out = ctx;
+    return PB3D_OK;
+}
+
+void pb3d_destroy(pb3d_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    pb3d_comm_destroy(ctx);
+    for (int i = 0; i < PB3D_NSCRATCH; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+int pb3d_device_info(pb3d_ctx* ctx, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_device_info: null context");
+    hipDeviceProp_t prop;
+    PB3D_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap > 0) {
+        snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return PB3D_OK;
+}
+
+int pb3d_sync(pb3d_ctx* ctx) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_sync: null context");
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_dev_alloc(pb3d_ctx* ctx, size_t bytes, void** dptr) {
+    PB3D_REQUIRE(ctx != nullptr && dptr != nullptr, "pb3d_dev_alloc: null argument");
+    *dptr = nullptr;
+    PB3D_HIP(hipSetDevice(ctx->device));
+    // round up so that 16-byte vector tails never leave the allocation
+    size_t padded = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    PB3D_HIP(hipMalloc(dptr, padded));
+    return PB3D_OK;
+}
+
+int pb3d_dev_free(pb3d_ctx* ctx, void* dptr) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_dev_free: null context");
+    if (!dptr) return PB3D_OK;
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_HIP(hipFree(dptr));
+    return PB3D_OK;
+}
+
+int pb3d_dev_memset(pb3d_ctx* ctx, void* dptr, int value, size_t bytes) {
+    PB3D_REQUIRE(ctx != nullptr && (dptr != nullptr || bytes == 0), "pb3d_dev_memset: null argument");
+    if (bytes) PB3D_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_h2d(pb3d_ctx* ctx, void* dptr, const void* hptr, size_t bytes) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_h2d: null context");
+    if (!bytes) return PB3D_OK;
+    PB3D_REQUIRE(dptr && hptr, "pb3d_h2d: null buffer");
+    PB3D_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_d2h(pb3d_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_d2h: null context");
+    if (!bytes) return PB3D_OK;
+    PB3D_REQUIRE(dptr && hptr, "pb3d_d2h: null buffer");
+    PB3D_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_d2d(pb3d_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_d2d: null context");
+    if (!bytes) return PB3D_OK;
+    PB3D_REQUIRE(dst && src, "pb3d_d2d: null buffer");
+    PB3D_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_event_create(pb3d_ctx* ctx, pb3d_event** ev) {
+    PB3D_REQUIRE(ctx != nullptr && ev != nullptr, "pb3d_event_create: null argument");
+    pb3d_event* e = (pb3d_event*)calloc(1, sizeof(pb3d_event));
+    if (!e) {
+        pb3d_set_error("pb3d_event_create: out of host memory");
+        return PB3D_ENOMEM;
+    }
+    hipError_t he = hipEventCreate(&e->ev);
+    if (he != hipSuccess) {
+        free(e);
+        pb3d_set_error("hipEventCreate failed: %s", hipGetErrorString(he));
+        return PB3D_ENODEVICE;
+    }
+    *ev = e;
+    return PB3D_OK;
+}
+
+int pb3d_event_record(pb3d_ctx* ctx, pb3d_event* ev) {
+    PB3D_REQUIRE(ctx != nullptr && ev != nullptr, "pb3d_event_record: null argument");
+    PB3D_HIP(hipEventRecord(ev->ev, ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_event_elapsed_ms(pb3d_ctx* ctx, pb3d_event* start, pb3d_event* stop, float* ms) {
+    PB3D_REQUIRE(ctx && start && stop && ms, "pb3d_event_elapsed_ms: null argument");
+    PB3D_HIP(hipEventSynchronize(stop->ev));
+    PB3D_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return PB3D_OK;
+}
+
+void pb3d_event_destroy(pb3d_event* ev) {
+    if (!ev) return;
+    (void)hipEventDestroy(ev->ev);
+    free(ev);
+}
+
+// ---- host shim H1 ------------------------------------------------------------------------------
+static const uint64_t k_rotinv_bits[91][9] = {
+#include "rotinv_table.inc"
+};
+
+int pb3d_rotinv(int angle_deg, double M[9]) {
+    PB3D_REQUIRE(M != nullptr, "pb3d_rotinv: null output");
+    PB3D_REQUIRE(angle_deg >= 0 && angle_deg <= 90, "pb3d_rotinv: angle %d outside the pinned table 0..90", angle_deg);
+    memcpy(M, k_rotinv_bits[angle_deg], sizeof(double) * 9);
+    return PB3D_OK;
+}
+
+int pb3d_offset(const double M[9], const int64_t shape[3], double off[3]) {
+    PB3D_REQUIRE(M && shape && off, "pb3d_offset: null argument");
+    // c - M@c, c = shape/2; NumPy's dgemv accumulates each row as fma(M2,c2, fma(M1,c1, M0*c0)).
+    const double c[3] = {(double)shape[0] / 2.0, (double)shape[1] / 2.0, (double)shape[2] / 2.0};
+    for (int h = 0; h < 3; ++h) {
+        double p = M[3 * h] * c[0];
+        p = std::fma(M[3 * h + 1], c[1], p);
+        p = std::fma(M[3 * h + 2], c[2], p);
+        off[h] = c[h] - p;
+    }
+    return PB3D_OK;
+}
+
+}  // extern "C"
+
+int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
+    PB3D_REQUIRE(ctx != nullptr && slot >= 0 && slot < PB3D_NSCRATCH, "pb3d_scratch: bad slot");
+    if (ctx->scratch_bytes[slot] < bytes || !ctx->scratch[slot]) {
+        if (ctx->scratch[slot]) {
+            PB3D_HIP(hipStreamSynchronize(ctx->stream));
+            PB3D_HIP(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        size_t padded = ((bytes ? bytes : 1) + 4095) & ~(size_t)4095;
+        PB3D_HIP(hipMalloc(&ctx->scratch[slot], padded));
+        ctx->scratch_bytes[slot] = padded;
+    }
+    *out = ctx->scratch[slot];
+    return PB3D_OK;
+}

@@ -1,0 +1,45 @@
+// global_carve (reference utils/voxel_carving_utils.py:269-298): ones((w,h,w)) -> process -> colour.
+#include "pb3d_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_transpose_mask(const u8* __restrict__ hw, u8* __restrict__ wh, i64 h, i64 w) {
+    const i64 n = h * w;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const i64 x = i / h, y = i - x * h;
+        wh[i] = hw[y * w + x] ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t* d_rgb_hw3, int64_t h, int64_t w,
+                          int angle_interval, int64_t x0, int64_t x1, uint8_t* d_out_slab) {
+    PB3D_REQUIRE(ctx != nullptr && h >= 0 && w >= 0, "pb3d_global_carve: bad shape");
+    PB3D_REQUIRE(angle_interval > 0, "pb3d_global_carve: angle_interval must be a positive integer (got %d)", angle_interval);
+    PB3D_REQUIRE(x0 >= 0 && x0 <= x1 && x1 <= w, "pb3d_global_carve: bad slab [%lld,%lld) of %lld", (long long)x0, (long long)x1,
+                 (long long)w);
+    const i64 W = w, H = h, D = w, nvox = W * H * D;
+    if (nvox == 0 || x1 == x0) return PB3D_OK;
+    PB3D_REQUIRE(d_bin_hw && d_rgb_hw3 && d_out_slab, "pb3d_global_carve: null buffer");
+    // generic pipeline on the full occupancy grid (rotation mixes x), colour only the slab
+    void *ones, *carved, *tmp, *mwh;
+    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &ones));
+    PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));
+    PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
+    PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));
+    PB3D_HIP(hipMemsetAsync(ones, 1, (size_t)nvox, ctx->stream));
+    hipLaunchKernelGGL(k_transpose_mask, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_bin_hw,
+                       (u8*)mwh, H, W);
+    PB3D_CHECK_LAUNCH();
+    PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
+    // colour apply is column-local: run it on the slab with a shifted rgb origin (rgb[y, x0 + xs])
+    // -> implemented by handing the kernel the full-width image and the slab's carved rows.
+    if (x0 == 0 && x1 == W) return pb3d_color_apply_dev(ctx, (const u8*)carved, W, H, D, d_rgb_hw3, d_out_slab);
+    pb3d_set_error("pb3d_global_carve: slab output needs the fused 90-degree path (angle_interval=90, w %% 16 == 0)");
+    return PB3D_EUNSUPPORTED;
+}
+
+}  // extern "C"

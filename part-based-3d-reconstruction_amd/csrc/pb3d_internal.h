@@ -1,0 +1,96 @@
+// Internal declarations shared by the translation units of libpb3d.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "pb3d.h"
+
+typedef uint8_t u8;
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#define PB3D_NSCRATCH 10
+
+struct pb3d_event {
+    hipEvent_t ev;
+};
+
+struct pb3d_ctx {
+    int device;
+    int cus;
+    hipStream_t stream;
+    // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
+    // hipFree per call once warm).
+    void* scratch[PB3D_NSCRATCH];
+    size_t scratch_bytes[PB3D_NSCRATCH];
+    // small pinned host area for counters read back from the device
+    void* pinned;
+    size_t pinned_bytes;
+    // state kept between pb3d_points_count and pb3d_points_fill (host-pointer flavour)
+    struct {
+        i64 A0, A1, A2, n;
+        int C, ncolors, stride;
+        u8 colors[3 * 32];
+        bool valid;
+    } pts;
+    // cached per-(x,z) source tables of permutation-like rotation steps
+    // RCCL (loaded lazily with dlopen; see comm.hip)
+    void* rccl_lib;
+    void* rccl_comm;
+    int rank, nranks;
+};
+
+// ---- error plumbing -------------------------------------------------------------------------
+void pb3d_set_error(const char* fmt, ...);
+
+#define PB3D_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            pb3d_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? PB3D_ENOMEM : PB3D_ENODEVICE;                    \
+        }                                                                                       \
+    } while (0)
+
+#define PB3D_TRY(call)                 \
+    do {                               \
+        int rc_ = (call);              \
+        if (rc_ != PB3D_OK) return rc_; \
+    } while (0)
+
+#define PB3D_REQUIRE(cond, ...)         \
+    do {                                \
+        if (!(cond)) {                  \
+            pb3d_set_error(__VA_ARGS__); \
+            return PB3D_EINVAL;         \
+        }                               \
+    } while (0)
+
+#define PB3D_CHECK_LAUNCH() PB3D_HIP(hipGetLastError())
+
+// scratch slot `slot` grown to at least `bytes`
+int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out);
+
+// grid size for grid-stride streaming kernels: enough blocks to fill 256 CUs, capped
+static inline unsigned pb3d_stream_blocks(const pb3d_ctx* ctx, i64 work_items, int per_block, int blocks_per_cu) {
+    i64 need = (work_items + per_block - 1) / per_block;
+    i64 cap = (i64)(ctx->cus > 0 ? ctx->cus : 256) * blocks_per_cu;
+    if (need < 1) need = 1;
+    return (unsigned)(need < cap ? need : cap);
+}
+
+// exact unsigned division by a runtime constant d (1 <= d < 2^31) for n < 2^32:
+// q = umulhi(n, m) >> s after an add-back; we keep it simple and exact with 64-bit math.
+struct pb3d_fastdiv {
+    u32 d;
+    u64 m;  // ceil(2^40 / d)  -> exact for n < 2^20 * ... (see fastdiv_make); fallback to '/' otherwise
+};
+
+// ---- kernels' host launchers used across translation units ---------------------------------
+int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
+                               const double off[3], const u8* d_mask_wh, u8* d_out);

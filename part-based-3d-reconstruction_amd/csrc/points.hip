@@ -1,0 +1,190 @@
+// K6: grid -> points.  Occupancy / colour-select with ORDERED stream compaction.
+//
+// reference utils/voxel_utils.py:7-21 (get_voxel_points_by_parts) and :35-51 (voxel_grid_to_points):
+// both end in numpy.where(mask), i.e. the selected voxels in C order of (a0,a1,a2).  An unordered
+// atomic append would break that, so compaction is a three-launch ordered scan: per-block popcounts
+// (wave64 ballots) -> exclusive scan of the block counts -> fill at base + in-block rank.
+#include "pb3d_internal.h"
+
+namespace {
+
+constexpr int kItems = 16;                 // 256-voxel sweeps per block
+constexpr int kBlockVox = 256 * kItems;    // lattice voxels per block
+
+struct SelParams {
+    i64 A1, A2;        // grid dims (axis 1, 2)
+    i64 L1, L2, nlat;  // lattice dims ([::s]) and total lattice voxels
+    int C, ncolors, stride;
+    u8 colors[3 * 32];
+};
+
+__device__ __forceinline__ i64 lattice_to_voxel(const SelParams& p, i64 li, i64* i0, i64* i1, i64* i2) {
+    if (p.stride == 1) {
+        *i2 = -1;  // coordinates derived lazily by the caller
+        return li;
+    }
+    const i64 a2 = li % p.L2;
+    const i64 r = li / p.L2;
+    const i64 a1 = r % p.L1, a0 = r / p.L1;
+    *i0 = a0; *i1 = a1; *i2 = a2;
+    return ((a0 * p.stride) * p.A1 + a1 * p.stride) * p.A2 + a2 * p.stride;
+}
+
+__device__ __forceinline__ bool selected(const SelParams& p, const u8* __restrict__ grid, i64 vox) {
+    const u8* g = grid + vox * p.C;
+    if (p.ncolors > 0) {
+        const u8 r = g[0], gg = g[1], b = g[2];
+        bool s = false;
+        for (int k = 0; k < p.ncolors; ++k) s |= (r == p.colors[3 * k]) & (gg == p.colors[3 * k + 1]) & (b == p.colors[3 * k + 2]);
+        return s;
+    }
+    bool s = false;
+    for (int c = 0; c < p.C; ++c) s |= g[c] != 0;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_points_count(const u8* __restrict__ grid, SelParams p, u32* __restrict__ block_counts) {
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const i64 base = (i64)blockIdx.x * kBlockVox;
+    u32 cnt = 0;
+    for (int it = 0; it < kItems; ++it) {
+        const i64 li = base + it * 256 + threadIdx.x;
+        bool sel = false;
+        if (li < p.nlat) {
+            i64 i0, i1, i2;
+            sel = selected(p, grid, lattice_to_voxel(p, li, &i0, &i1, &i2));
+        }
+        cnt += (u32)__popcll(__ballot(sel));
+    }
+    if (lane == 0) wsum[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of nb block counts into 64-bit offsets; single block, nb is at most a few 100k.
+__global__ __launch_bounds__(1024) void k_scan_counts(const u32* __restrict__ counts, i64* __restrict__ offsets, i64 nb,
+                                                      i64* __restrict__ total) {
+    __shared__ i64 part[1024];
+    const i64 per = (nb + 1023) / 1024;
+    const i64 b = (i64)threadIdx.x * per;
+    const i64 e = b + per < nb ? b + per : nb;
+    i64 s = 0;
+    for (i64 i = b; i < e; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i64 run = 0;
+        for (int i = 0; i < 1024; ++i) { const i64 v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    i64 run = part[threadIdx.x];
+    for (i64 i = b; i < e; ++i) { offsets[i] = run; run += counts[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_points_fill(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
+                                                     float* __restrict__ pts, u8* __restrict__ cols) {
+    __shared__ u32 segoff[kItems * 4 + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const i64 base = (i64)blockIdx.x * kBlockVox;
+    u64 bal[kItems];
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const i64 li = base + it * 256 + threadIdx.x;
+        bool sel = false;
+        if (li < p.nlat) {
+            i64 i0, i1, i2;
+            sel = selected(p, grid, lattice_to_voxel(p, li, &i0, &i1, &i2));
+        }
+        bal[it] = __ballot(sel);
+        if (lane == 0) segoff[it * 4 + w] = (u32)__popcll(bal[it]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int i = 0; i < kItems * 4; ++i) { const u32 v = segoff[i]; segoff[i] = run; run += v; }
+    }
+    __syncthreads();
+    const i64 out0 = block_off[blockIdx.x];
+    const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        if (!((bal[it] >> lane) & 1)) continue;
+        const i64 li = base + it * 256 + threadIdx.x;
+        const i64 a2 = li % p.L2;
+        const i64 r = li / p.L2;
+        const i64 a1 = r % p.L1, a0 = r / p.L1;
+        const i64 vox = ((a0 * p.stride) * p.A1 + a1 * p.stride) * p.A2 + a2 * p.stride;
+        const i64 pos = out0 + segoff[it * 4 + w] + __popcll(bal[it] & lt);
+        const float s = (float)p.stride;
+        pts[3 * pos + 0] = __fmul_rn((float)a2, s);
+        pts[3 * pos + 1] = __fmul_rn((float)a1, s);
+        pts[3 * pos + 2] = __fmul_rn((float)a0, s);
+        for (int c = 0; c < p.C; ++c) cols[p.C * pos + c] = grid[vox * p.C + c];
+    }
+}
+
+int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, int stride, SelParams* p) {
+    PB3D_REQUIRE(A0 >= 0 && A1 >= 0 && A2 >= 0 && (C == 1 || C == 3), "pb3d_points: bad shape (%lld,%lld,%lld,%d)",
+                 (long long)A0, (long long)A1, (long long)A2, C);
+    PB3D_REQUIRE(stride >= 1, "pb3d_points: stride must be >= 1");
+    PB3D_REQUIRE(ncolors >= 0 && ncolors <= 32, "pb3d_points: at most 32 colours");
+    PB3D_REQUIRE(ncolors == 0 || (C == 3 && colors), "pb3d_points: colour selection needs an RGB grid");
+    p->A1 = A1; p->A2 = A2;
+    const i64 L0 = (A0 + stride - 1) / stride;
+    p->L1 = (A1 + stride - 1) / stride; p->L2 = (A2 + stride - 1) / stride;
+    p->nlat = L0 * p->L1 * p->L2;
+    p->C = C; p->ncolors = ncolors; p->stride = stride;
+    memset(p->colors, 0, sizeof(p->colors));
+    if (ncolors) memcpy(p->colors, colors, (size_t)3 * ncolors);
+    return PB3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C,
+                          const uint8_t* colors, int ncolors, int stride, int64_t* n) {
+    PB3D_REQUIRE(ctx != nullptr && n != nullptr, "pb3d_points_count: null argument");
+    SelParams p;
+    PB3D_TRY(make_params(A0, A1, A2, C, colors, ncolors, stride, &p));
+    *n = 0;
+    if (p.nlat == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid != nullptr, "pb3d_points_count: null grid");
+    const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
+    PB3D_REQUIRE(nb < (1ll << 31), "pb3d_points_count: grid too large");
+    void *counts, *offsets;
+    PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)nb * sizeof(u32), &counts));
+    PB3D_TRY(pb3d_scratch(ctx, 9, (size_t)(nb + 1) * sizeof(i64), &offsets));
+    hipLaunchKernelGGL(k_points_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
+    PB3D_CHECK_LAUNCH();
+    i64* total = (i64*)offsets + nb;
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)counts, (i64*)offsets, nb, total);
+    PB3D_CHECK_LAUNCH();
+    PB3D_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    *n = *(i64*)ctx->pinned;
+    return PB3D_OK;
+}
+
+// Must follow pb3d_points_count_dev with identical arguments on the same context (the scanned block
+// offsets stay in the context's scratch).  d_pts: n*3 floats, d_cols: n*C bytes.
+int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C,
+                         const uint8_t* colors, int ncolors, int stride, int64_t n, float* d_pts, uint8_t* d_cols) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_points_fill: null context");
+    SelParams p;
+    PB3D_TRY(make_params(A0, A1, A2, C, colors, ncolors, stride, &p));
+    if (p.nlat == 0 || n == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid && d_pts && d_cols, "pb3d_points_fill: null buffer");
+    const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
+    PB3D_REQUIRE(ctx->scratch[9] && ctx->scratch_bytes[9] >= (size_t)(nb + 1) * sizeof(i64),
+                 "pb3d_points_fill: call pb3d_points_count first");
+    hipLaunchKernelGGL(k_points_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9],
+                       d_pts, d_cols);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+}  // extern "C"

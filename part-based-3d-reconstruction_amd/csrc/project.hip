@@ -1,0 +1,174 @@
+// K7 pinhole scatter projection (deterministic last-writer-wins) and K8 per-part IoU counts.
+//
+// reference utils/projection_utils.py:5-23:  pc = (p - cam) @ R.T ; Z<1e-8 -> 1e-8 ;
+//   u = (X/Z)*f + cx ; v = -(Y/Z)*f + cy ; rint ; bounds ; img[v,u] = colour.
+// NumPy's fancy assignment resolves duplicate pixels by "last in input order wins"; that is
+// reproduced with an atomicMax on (point index + 1) per pixel followed by a resolve pass, so the
+// image is identical from run to run and to the CPU path.
+// Arithmetic: each component of pc is the FMA chain fma(d2,r2, fma(d1,r1, d0*r0)) NumPy's gemm
+// produces (float32 or float64 per prec[0]); the later stages are separate IEEE ops whose width is
+// prec[1..3].  float32 +,-,*,/ are evaluated in double and rounded once (exact since 53 >= 2*24+2);
+// the float32 FMA chain uses the hardware's single-rounded v_fma_f32.
+#include "pb3d_internal.h"
+
+namespace {
+
+struct ProjParams {
+    double R[9], cam[3], f, cx, cy;
+    int t0, tm, tu, tv;
+    int Himg, Wimg, pts_f64;
+};
+
+__device__ __forceinline__ double rnd(double v, int is64) { return is64 ? v : (double)(float)v; }
+
+__device__ __forceinline__ bool project_point(const ProjParams& P, const void* __restrict__ pts, i64 i, int* ui, int* vi) {
+    double p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        p[k] = P.pts_f64 ? ((const double*)pts)[3 * i + k] : (double)((const float*)pts)[3 * i + k];
+    double pc[3];
+    if (P.t0) {
+        const double d0 = __dsub_rn(p[0], P.cam[0]), d1 = __dsub_rn(p[1], P.cam[1]), d2 = __dsub_rn(p[2], P.cam[2]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            pc[r] = __fma_rn(d2, P.R[3 * r + 2], __fma_rn(d1, P.R[3 * r + 1], __dmul_rn(d0, P.R[3 * r])));
+    } else {
+        const float d0 = __fsub_rn((float)p[0], (float)P.cam[0]), d1 = __fsub_rn((float)p[1], (float)P.cam[1]),
+                    d2 = __fsub_rn((float)p[2], (float)P.cam[2]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            pc[r] = (double)__fmaf_rn(d2, (float)P.R[3 * r + 2],
+                                      __fmaf_rn(d1, (float)P.R[3 * r + 1], __fmul_rn(d0, (float)P.R[3 * r])));
+    }
+    const double X = pc[0], Y = pc[1];
+    double Z = pc[2];
+    const double zmin = P.t0 ? 1e-8 : (double)(float)1e-8;
+    if (Z < zmin) Z = zmin;
+    const double qx = rnd(__ddiv_rn(X, Z), P.t0);
+    const double qy = -rnd(__ddiv_rn(Y, Z), P.t0);
+    const double fm = P.tm ? P.f : (double)(float)P.f;
+    const double mu = rnd(__dmul_rn(qx, fm), P.tm), mv = rnd(__dmul_rn(qy, fm), P.tm);
+    const double u = rnd(__dadd_rn(mu, P.tu ? P.cx : (double)(float)P.cx), P.tu);
+    const double v = rnd(__dadd_rn(mv, P.tv ? P.cy : (double)(float)P.cy), P.tv);
+    const double ur = rint(u), vr = rint(v);
+    if (!(ur >= 0.0 && ur < (double)P.Wimg && vr >= 0.0 && vr < (double)P.Himg)) return false;  // NaN -> false
+    *ui = (int)ur; *vi = (int)vr;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_project_points(const void* __restrict__ pts, i64 n, ProjParams P,
+                                                        u32* __restrict__ winner) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        int ui, vi;
+        if (project_point(P, pts, i, &ui, &vi)) atomicMax(&winner[(i64)vi * P.Wimg + ui], (u32)(i + 1));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_project_resolve(const u32* __restrict__ winner, const u8* __restrict__ cols,
+                                                         u8* __restrict__ img, i64 npix) {
+    for (i64 px = (i64)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (i64)gridDim.x * blockDim.x) {
+        const u32 w = winner[px];
+        u8 r = 0, g = 0, b = 0;
+        if (w) {
+            const u8* c = cols + (i64)(w - 1) * 3;
+            r = c[0]; g = c[1]; b = c[2];
+        }
+        img[3 * px] = r; img[3 * px + 1] = g; img[3 * px + 2] = b;
+    }
+}
+
+struct IouParams {
+    int ncolors;
+    u8 colors[3 * 32];
+};
+
+__global__ __launch_bounds__(256) void k_partwise_iou(const u8* __restrict__ a, const u8* __restrict__ b, i64 npix,
+                                                      IouParams P, unsigned long long* __restrict__ counts) {
+    __shared__ u32 acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 nloop = (npix + stride - 1) / stride;  // same trip count for every lane: ballots stay convergent
+    for (i64 it = 0; it < nloop; ++it) {
+        const i64 px = it * stride + (i64)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = px < npix;
+        u8 a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+        if (live) {
+            a0 = a[3 * px]; a1 = a[3 * px + 1]; a2 = a[3 * px + 2];
+            b0 = b[3 * px]; b1 = b[3 * px + 1]; b2 = b[3 * px + 2];
+        }
+        for (int k = 0; k < P.ncolors; ++k) {
+            const u8 c0 = P.colors[3 * k], c1 = P.colors[3 * k + 1], c2 = P.colors[3 * k + 2];
+            const bool ma = live && a0 == c0 && a1 == c1 && a2 == c2;
+            const bool mb = live && b0 == c0 && b1 == c1 && b2 == c2;
+            const u32 ni = (u32)__popcll(__ballot(ma && mb)), nu = (u32)__popcll(__ballot(ma || mb));
+            if (lane == 0) {
+                if (ni) atomicAdd(&acc[2 * k], ni);
+                if (nu) atomicAdd(&acc[2 * k + 1], nu);
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * P.ncolors && acc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pb3d_project_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_t* d_cols, int64_t n,
+                     const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4],
+                     int Himg, int Wimg, uint8_t* d_img) {
+    PB3D_REQUIRE(ctx && R && cam && prec, "pb3d_project: null argument");
+    PB3D_REQUIRE(n >= 0 && n < 0xffffffffll, "pb3d_project: point count out of range");
+    PB3D_REQUIRE(Himg >= 0 && Wimg >= 0, "pb3d_project: bad image shape");
+    const i64 npix = (i64)Himg * Wimg;
+    if (npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_img && (n == 0 || (d_pts && d_cols)), "pb3d_project: null buffer");
+    for (int k = 0; k < 4; ++k) PB3D_REQUIRE(prec[k] == 0 || prec[k] == 1, "pb3d_project: prec[%d] must be 0 or 1", k);
+    PB3D_REQUIRE(prec[1] >= prec[0] && prec[2] >= prec[1] && prec[3] >= prec[1], "pb3d_project: precision may only widen");
+    void* winner;
+    PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)npix * sizeof(u32), &winner));
+    PB3D_HIP(hipMemsetAsync(winner, 0, (size_t)npix * sizeof(u32), ctx->stream));
+    ProjParams P;
+    memcpy(P.R, R, sizeof(P.R)); memcpy(P.cam, cam, sizeof(P.cam));
+    P.f = f; P.cx = cx; P.cy = cy;
+    P.t0 = prec[0]; P.tm = prec[1]; P.tu = prec[2]; P.tv = prec[3];
+    P.Himg = Himg; P.Wimg = Wimg; P.pts_f64 = pts_f64 ? 1 : 0;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_project_points, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_pts, n, P,
+                           (u32*)winner);
+        PB3D_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_project_resolve, dim3(pb3d_stream_blocks(ctx, npix, 256, 8)), dim3(256), 0, ctx->stream,
+                       (const u32*)winner, d_cols, d_img, npix);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64_t npix,
+                          const uint8_t* colors, int ncolors, int64_t* inter, int64_t* uni) {
+    PB3D_REQUIRE(ctx && inter && uni, "pb3d_partwise_iou: null argument");
+    PB3D_REQUIRE(ncolors >= 0 && ncolors <= 32 && npix >= 0, "pb3d_partwise_iou: bad sizes");
+    for (int k = 0; k < ncolors; ++k) inter[k] = uni[k] = 0;
+    if (ncolors == 0 || npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_a && d_b && colors, "pb3d_partwise_iou: null buffer");
+    void* counts;
+    PB3D_TRY(pb3d_scratch(ctx, 9, 64 * sizeof(unsigned long long), &counts));
+    PB3D_HIP(hipMemsetAsync(counts, 0, 64 * sizeof(unsigned long long), ctx->stream));
+    IouParams P;
+    P.ncolors = ncolors;
+    memset(P.colors, 0, sizeof(P.colors));
+    memcpy(P.colors, colors, (size_t)3 * ncolors);
+    hipLaunchKernelGGL(k_partwise_iou, dim3(pb3d_stream_blocks(ctx, npix, 256, 4)), dim3(256), 0, ctx->stream, d_a, d_b, npix, P,
+                       (unsigned long long*)counts);
+    PB3D_CHECK_LAUNCH();
+    PB3D_HIP(hipMemcpyAsync(ctx->pinned, counts, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned long long* h = (const unsigned long long*)ctx->pinned;
+    for (int k = 0; k < ncolors; ++k) { inter[k] = (int64_t)h[2 * k]; uni[k] = (int64_t)h[2 * k + 1]; }
+    return PB3D_OK;
+}
+
+}  // extern "C"

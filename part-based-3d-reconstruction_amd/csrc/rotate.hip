@@ -1,0 +1,180 @@
+// K2: rotate-about-Y (trilinear, uint8 rounding) + mask carve, and the process_voxel_grid loop.
+//
+// Bit-exact restatement of scipy.ndimage.affine_transform(order=1, mode="constant", cval=0) as the
+// reference calls it (reference utils/voxel_carving_utils.py:116-123), for matrices whose row 1 is
+// [+-0, 1, +-0] with off[1] == 0 (every Rinv(angle) the reference can produce).  Then cc1 == y
+// exactly, the y-weights are {1, 0}, and per output voxel the arithmetic is
+//     cc_h = (((0 + x*M[h][0]) + y*M[h][1]) + z*M[h][2]) + off[h]       h = 0, 2   (IEEE, NO fma)
+//     outside [0, n_h - 1]  -> 0
+//     t = cc - floor(cc);  w0 = 1 - t;  w1 = 1 - w0
+//     acc = ((v00*wx0)*wz0 + (v01*wx0)*wz1) + (v10*wx1)*wz0 + (v11*wx1)*wz1    (left to right)
+//     out = acc > 0 ? (uint8)min(acc + 0.5, 255) : 0
+// All doubles are evaluated with __dmul_rn/__dadd_rn so that no contraction can occur; the file is
+// also compiled with -ffp-contract=off.  The coordinates depend on (x,z) only, so a thread computes
+// them once and re-uses them for every Y-plane of its chunk (the FP64 work is amortised over y).
+#include "pb3d_internal.h"
+
+namespace {
+
+struct RotParams {
+    double m00, m01, m02, off0;
+    double m20, m21, m22, off2;
+};
+
+struct Cell {
+    double wx0, wx1, wz0, wz1;
+    int s0, s2;  // floor of the source coordinate; s0 < 0 marks "outside -> 0"
+};
+
+__device__ __forceinline__ double coord(double x, double z, double ma, double mb, double mc, double off) {
+    // (((0 + x*ma) + y*mb) + z*mc) + off with y*mb == +-0 for every y >= 0 (mb is +-0)
+    double c = __dadd_rn(0.0, __dmul_rn(x, ma));
+    c = __dadd_rn(c, __dmul_rn(0.0, mb));
+    c = __dadd_rn(c, __dmul_rn(z, mc));
+    return __dadd_rn(c, off);
+}
+
+__device__ __forceinline__ Cell make_cell(const RotParams& p, i64 x, i64 z, i64 W, i64 D) {
+    Cell c;
+    const double cc0 = coord((double)x, (double)z, p.m00, p.m01, p.m02, p.off0);
+    const double cc2 = coord((double)x, (double)z, p.m20, p.m21, p.m22, p.off2);
+    if (cc0 < 0.0 || cc0 > (double)(W - 1) || cc2 < 0.0 || cc2 > (double)(D - 1)) {
+        c.s0 = -1; c.s2 = 0; c.wx0 = c.wx1 = c.wz0 = c.wz1 = 0.0;
+        return c;
+    }
+    const double f0 = floor(cc0), f2 = floor(cc2);
+    c.s0 = (int)f0; c.s2 = (int)f2;
+    c.wx0 = __dsub_rn(1.0, __dsub_rn(cc0, f0));
+    c.wx1 = __dsub_rn(1.0, c.wx0);
+    c.wz0 = __dsub_rn(1.0, __dsub_rn(cc2, f2));
+    c.wz1 = __dsub_rn(1.0, c.wz0);
+    return c;
+}
+
+// value of one output voxel from plane y of `in`; taps with an exactly-zero weight add +0.0 and are
+// skipped (this also keeps the index in range: a tap beyond n-1 only ever occurs with weight 0).
+__device__ __forceinline__ u32 sample(const u8* __restrict__ in, const Cell& c, i64 y, i64 H, i64 D) {
+    if (c.s0 < 0) return 0;
+    const u8* r0 = in + ((i64)c.s0 * H + y) * D + c.s2;
+    const u8* r1 = r0 + H * D;
+    double acc = 0.0;
+    const bool x1 = c.wx1 != 0.0, z1 = c.wz1 != 0.0;
+    // weights are >= 0; a zero wx0/wz0 (never happens: w0 = 1 - t > 0) needs no special case
+    acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r0[0], c.wx0), c.wz0));
+    if (z1) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r0[1], c.wx0), c.wz1));
+    if (x1) {
+        acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r1[0], c.wx1), c.wz0));
+        if (z1) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r1[1], c.wx1), c.wz1));
+    }
+    if (!(acc > 0.0)) return 0;
+    acc = __dadd_rn(acc, 0.5);
+    if (acc > 255.0) acc = 255.0;
+    return (u32)acc;  // truncation
+}
+
+// Tile: 4 x-rows (one per wavefront) by 256 z (4 consecutive z per lane), swept over TY planes.
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ in, u8* __restrict__ out,
+                                                        const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D,
+                                                        int TY) {
+    const int lane = threadIdx.x & 63;
+    const i64 x = (i64)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 z0 = ((i64)blockIdx.x * 64 + lane) * 4;
+    if (x >= W || z0 >= D) return;
+    const i64 y_beg = (i64)blockIdx.z * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    Cell c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (z0 + q < D) c[q] = make_cell(p, x, z0 + q, W, D);
+        else { c[q].s0 = -1; c[q].s2 = 0; c[q].wx0 = c[q].wx1 = c[q].wz0 = c[q].wz1 = 0.0; }
+    }
+    for (i64 y = y_beg; y < y_end; ++y) {
+        const bool keep = mask_wh ? mask_wh[x * H + y] != 0 : true;  // wave-uniform
+        u32 r[4] = {0, 0, 0, 0};
+        if (keep) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = sample(in, c[q], y, H, D);
+        }
+        u8* o = out + (x * H + y) * D + z0;
+        if (PACK) {
+            *(u32*)o = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (z0 + q < D) o[q] = (u8)r[q];
+        }
+    }
+}
+
+bool is_zero(double v) { return v == 0.0; }
+
+}  // namespace
+
+int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
+                               const double off[3], const u8* d_mask_wh, u8* d_out) {
+    PB3D_REQUIRE(is_zero(M[3]) && M[4] == 1.0 && is_zero(M[5]) && is_zero(M[1]) && is_zero(M[7]) && is_zero(off[1]),
+                 "pb3d_rotate_carve: matrix is not a rotation about Y (row 1 must be [0,1,0], M[0][1]=M[2][1]=0, off[1]=0)");
+    PB3D_REQUIRE(W < (1ll << 30) && D < (1ll << 30), "pb3d_rotate_carve: axis too long");
+    if (W * H * D == 0) return PB3D_OK;
+    RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    int TY = 16;
+    // keep at least ~8 blocks per CU in flight for small grids
+    const i64 tiles_xz = ((D + 255) / 256) * ((W + 3) / 4);
+    while (TY > 1 && tiles_xz * ((H + TY - 1) / TY) < (i64)ctx->cus * 8) TY >>= 1;
+    dim3 grid((unsigned)((D + 255) / 256), (unsigned)((W + 3) / 4), (unsigned)((H + TY - 1) / TY));
+    PB3D_REQUIRE(grid.y <= 65535u * 1024u && grid.z <= 65535u, "pb3d_rotate_carve: grid too large");
+    const bool pack = (D % 4 == 0) && (((uintptr_t)d_out & 3u) == 0);
+    if (pack)
+        hipLaunchKernelGGL(k_rotate_generic<true>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY);
+    else
+        hipLaunchKernelGGL(k_rotate_generic<false>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+extern "C" {
+
+int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
+                          const double M[9], const double off[3], const uint8_t* d_mask_wh, uint8_t* d_out) {
+    PB3D_REQUIRE(ctx != nullptr && M && off, "pb3d_rotate_carve: null argument");
+    PB3D_REQUIRE(W >= 0 && H >= 0 && D >= 0, "pb3d_rotate_carve: bad shape");
+    if (W * H * D == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_occ && d_out && d_occ != d_out, "pb3d_rotate_carve: null or aliased buffer");
+    return pb3d_launch_rotate_generic(ctx, d_occ, W, H, D, M, off, d_mask_wh, d_out);
+}
+
+int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
+                          const uint8_t* d_mask_wh, int angle_interval, uint8_t* d_out, uint8_t* d_tmp) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_process_grid: null context");
+    PB3D_REQUIRE(W >= 0 && H >= 0 && D >= 0, "pb3d_process_grid: bad shape");
+    PB3D_REQUIRE(angle_interval > 0, "pb3d_process_grid: angle_interval must be a positive integer (got %d)", angle_interval);
+    const i64 nvox = W * H * D;
+    if (nvox == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_occ && d_mask_wh && d_out && d_tmp, "pb3d_process_grid: null buffer");
+    PB3D_REQUIRE(d_out != d_occ && d_tmp != d_occ && d_tmp != d_out, "pb3d_process_grid: buffers must not alias");
+    const int nsteps = 90 / angle_interval + 1;  // len(range(0, 91, k))
+    const i64 shape[3] = {W, H, D};
+    // ping-pong so that the last step lands in d_out
+    const u8* src = d_occ;
+    for (int s = 0; s < nsteps; ++s) {
+        const int angle = s * angle_interval;
+        double M[9], off[3];
+        PB3D_TRY(pb3d_rotinv(angle, M));
+        PB3D_TRY(pb3d_offset(M, shape, off));
+        u8* dst = ((nsteps - 1 - s) % 2 == 0) ? d_out : d_tmp;
+        bool ident = off[0] == 0.0 && off[1] == 0.0 && off[2] == 0.0;
+        for (int k = 0; k < 9; ++k) ident = ident && M[k] == ((k % 4 == 0) ? 1.0 : 0.0);
+        if (ident) {
+            // Rinv(0) is exactly I with zero offset: every coordinate is the integer itself, the
+            // weights are {1,0}, acc == v and (uint8)(v + 0.5) == v -- the step is the carve alone.
+            PB3D_TRY(pb3d_carve_mask_dev(ctx, src, W, H, D, 1, d_mask_wh, dst));
+        } else {
+            PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst));
+        }
+        src = dst;
+    }
+    return PB3D_OK;
+}
+
+}  // extern "C"
