@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the semantic voxel-carving hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run,
+                                                              one rank per GPU; RANK/LOCAL_RANK/... from env)
+
+Workload = BASELINE.json configs[3]: synthetic 16-label mask, 1024^3 semantic RGB grid (M1 of
+SURVEY.md 8(d): carve_voxel_grid_with_masks(sem1024, binary), 6 algorithmic bytes per voxel).
+One "step" = one carve of the whole 1024^3 grid, inputs resident in HBM.  With N ranks the grid is
+cut into N slabs along axis 0 (contiguous; no data-path collective), every rank carves its slab
+(strong scaling), the timed region is K steps between barrier + device sync on both sides and the
+MAX over ranks is taken.  The slab all-gather (RCCL over xGMI) that reassembles the carved volume is
+timed separately in the same run and reported in "allgather" (see DESIGN.md for why it cannot be
+inside `value`).  No PyTorch anywhere: ctypes -> libpb3d.so -> hand-written HIP kernels.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "part-based-3d-reconstruction_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_VOXEL = 6        # M1: read 3 + write 3
+
+
+def cpu_baseline(S, d_in, m_wh, planes):
+    """The CPU oracle (oracle/pb3d_oracle.c, a port of the reference's np.where carve) timed on this
+    box's host cores on a bounded sample: the first `planes` X-planes of the same synthetic grid."""
+    from oracle import oracle as orc
+    sample = d_in.download((planes, S, S, 3))
+    mask = np.ascontiguousarray(m_wh[:planes])
+    nvox = planes * S * S
+    cores = orc.get_threads()
+    best = None
+    t_all = time.perf_counter()
+    out = None
+    for _ in range(5):
+        t0 = time.perf_counter()
+        out = orc.carve_voxel_grid_with_masks(sample, mask if planes != S else mask.T)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        if time.perf_counter() - t_all > 20:
+            break
+    # the expression the reference itself executes (utils/voxel_carving_utils.py:87), single-threaded NumPy
+    t0 = time.perf_counter()
+    ref_form = np.where(mask[:, :, None, None].astype(bool), sample, 0)
+    t_np = time.perf_counter() - t0
+    assert np.array_equal(ref_form, out)
+    return {"value": round(nvox / best / 1e6, 1), "unit": "Mvoxel/s", "cores": cores, "kind": "port",
+            "sample": f"first {planes} of {S} X-planes of the same synthetic grid ({nvox / 1e6:.0f} Mvoxel, best of <=5 passes)",
+            "numpy_where_1core_Mvoxel_s": round(nvox / t_np / 1e6, 1)}, out
+
+
+def pmc_traffic(kernel_substr, nvox):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches this workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        for rec in json.load(open(path)):
+            if kernel_substr in rec.get("kernel", "") and rec.get("voxels_per_launch") == nvox:
+                return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024, help="grid edge (1024 = the BASELINE metric's config)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    os.environ["PB3D_DEVICE"] = str(local_rank)
+
+    import pb3d
+    from pb3d import device as dev
+    from pb3d import dist as pdist
+    from pb3d.rendezvous import ControlPlane
+
+    cp = ControlPlane(rank, world)
+    S = args.size
+    pb3d._lib.ctx()
+    info = dev.device_info()
+
+    planes = pdist.equal_slabs(S, world)
+    x0, x1 = rank * planes, (rank + 1) * planes
+    slab_vox = planes * S * S
+    slab_bytes = slab_vox * 3
+    d_in = dev.DeviceBuffer(slab_bytes)
+    d_full = dev.DeviceBuffer(slab_bytes * world)        # the reassembled volume; this rank's slab lives at its slot
+    d_out = d_full.at(rank * slab_bytes)
+    d_mwh = dev.DeviceBuffer(S * S)
+    dev.synth_sem(x0, x1, S, S, args.seed, d_in)
+    dev.synth_mask16(S, d_binary_wh=d_mwh)
+    d_mslab = d_mwh.at(x0 * S)
+    dev.sync()
+
+    def step():
+        dev.carve_mask(d_in, planes, S, S, 3, d_mslab, d_out)
+
+    for _ in range(args.warmup):
+        step()
+    dev.sync()
+    cp.barrier()
+    e0, e1 = dev.Event(), dev.Event()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    dev.sync()
+    t_local = time.perf_counter() - t0
+    cp.barrier()
+    t = cp.allreduce_max(t_local)
+    kernel_ms = e1.elapsed_ms_since(e0) / args.steps     # HIP events on the stream the kernel runs on
+    kernel_ms_max = cp.allreduce_max(kernel_ms)
+
+    total_vox = S * S * S
+    value = total_vox * args.steps / t / 1e6
+    achieved = ALG_BYTES_PER_VOXEL * slab_vox / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "Mvoxel/s carved (semantic carve, 1024^3 grid)", "value": round(value, 1), "unit": "Mvoxel/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"configs[3]: synthetic 16-label mask, {S}^3 semantic RGB grid, op M1 "
+                               f"carve_voxel_grid_with_masks(sem, binary); X-slab partition over {world} GPU(s)",
+                   "grid": [S, S, S, 3], "slab_planes_per_gpu": planes, "seed": args.seed, "device": info["name"]},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_carve_cols", slab_vox),
+                     "kernel": "k_carve_cols", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
+                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_VOXEL * slab_vox},
+    }
+
+    if world > 1 and not args.no_allgather:
+        uid = cp.broadcast(pdist.new_unique_id().tobytes() if rank == 0 else None)
+        pdist.comm_init(np.frombuffer(uid, np.uint8), rank, world)
+        for _ in range(2):
+            pdist.allgather(d_out, d_full, slab_bytes)
+        dev.sync(); cp.barrier()
+        g0, g1 = dev.Event(), dev.Event()
+        reps = 5
+        g0.record()
+        for _ in range(reps):
+            pdist.allgather(d_out, d_full, slab_bytes)
+        g1.record(); dev.sync()
+        ag_ms = cp.allreduce_max(g1.elapsed_ms_since(g0) / reps)
+        # carve + reassembly on one stream, back to back
+        cp.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step(); pdist.allgather(d_out, d_full, slab_bytes)
+        dev.sync()
+        t_both = cp.allreduce_max(time.perf_counter() - t0) / reps
+        out["allgather"] = {"form": "rgb slabs, in place, one ncclAllGather", "bytes_per_rank": slab_bytes,
+                            "ms": round(ag_ms, 4), "busbw_GB_s": round(slab_bytes * (world - 1) / (ag_ms * 1e-3) / 1e9, 1),
+                            "value_incl_allgather_Mvoxel_s": round(total_vox / t_both / 1e6, 1)}
+        # reassembled volume sanity: neighbour's slab arrived (first plane of rank (r+1)%world is not all zero)
+        nb = (rank + 1) % world
+        probe = d_full.download((1, S, S, 3), byte_offset=nb * slab_bytes + (S // 2) * S * 3 * 0)
+        out["allgather"]["checked"] = bool(probe.any())
+        pdist.comm_destroy()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        lab_planes = min(S, 128)
+        m_wh = d_mwh.download((S, S))
+        base, cpu_out = cpu_baseline(S, d_in, m_wh, lab_planes)
+        gpu_out = d_full.download((lab_planes, S, S, 3))
+        assert np.array_equal(gpu_out, cpu_out), "GPU carve differs from the CPU oracle on the sample"
+        base["gpu_matches_on_sample"] = True
+        out["cpu_baseline"] = base
+    cp.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    cp.close()
+    for b in (d_in, d_full, d_mwh):
+        b.free()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""CPU-only, world_size 2 over gloo: the slab sharding of the carve path and its single all-gather
+reassembly give byte-for-byte the single-process result.  Each rank carves its slab with the CPU
+oracle standing in for the device kernel (the partition / reassembly logic is what is under test;
+the per-slab kernels are checked against the same oracle in the GPU parity tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch
+        import torch.distributed as dist
+        import synth_host
+        from oracle import oracle as orc
+        from pb3d.dist import slab_bounds
+        orc.set_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        S = 32
+        lab, binary, rgb = synth_host.mask16(S)
+        # (a) M1: semantic carve of a sharded RGB grid, even partition -> one all_gather
+        x0, x1 = slab_bounds(S, rank, world)
+        slab_in = synth_host.sem_slab(x0, x1, S, S, seed=1)
+        m_wh = np.ascontiguousarray(binary.T)
+        slab_out = orc.carve_voxel_grid_with_masks(slab_in, m_wh[x0:x1])     # mask rows of this slab's planes
+        parts = [torch.empty_like(torch.from_numpy(slab_out)) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(slab_out))
+        full = np.concatenate([p.numpy() for p in parts], axis=0)
+        # full grid is square in (W,H): the (H,W) test of _mask_to_wh wins, so hand it the (H,W) image
+        want = orc.carve_voxel_grid_with_masks(synth_host.sem_slab(0, S, S, S, seed=1), binary)
+        ok_a = np.array_equal(full, want)
+        # (b) global_carve: output X-slab of a replicated-input job (the slab of the full result)
+        g_full = orc.global_carve(binary, rgb, 90)
+        mine = np.ascontiguousarray(g_full[x0:x1])
+        parts = [torch.empty_like(torch.from_numpy(mine)) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(mine))
+        ok_b = np.array_equal(np.concatenate([p.numpy() for p in parts], axis=0), g_full)
+        # (c) uneven partition (S=31 planes over 2 ranks): bounds still tile the axis exactly
+        b = [slab_bounds(31, r, world) for r in range(world)]
+        ok_c = b[0][0] == 0 and b[-1][1] == 31 and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        # (d) max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([0.25 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok_d = float(t) == 0.25 + world - 1
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok_a, ok_b, ok_c, ok_d))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), str(e), None))
+
+
+@pytest.mark.timeout(300)
+def test_sharded_carve_world2_gloo():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1:] == (True, True, True, True), r

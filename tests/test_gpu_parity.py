@@ -1,0 +1,283 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the hand-written HIP path, called through the
+C-ABI by the NumPy shim, must be BIT-EXACT with (i) the golden vectors captured from the reference
+and (ii) the CPU oracle on seeded inputs -- integer / byte / index work, so the bar is equality."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+JOBS_NB1 = [(["full_building"], 90), (["chhatris"], 90), (["plinth"], 90), (["front_minarets"], 90),
+            (["small_minarets"], 90), (["dome"], 90)]
+JOBS_MIXED = [(["full_building", "plinth"], 90), (["chhatris"], 45), (["dome"], 60), (["front_minarets", "small_minarets"], 90)]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_native_library_is_loaded(pb3d_gpu):
+    """The extension that runs is the in-tree libpb3d.so (no eager/CPU path exists to fall back to)."""
+    maps = open("/proc/self/maps").read()
+    assert "libpb3d.so" in maps
+    info = __import__("pb3d").device.device_info()
+    assert "gfx950" in info["name"], info
+
+
+# ---- golden vectors from the reference ----------------------------------------------------------------
+def test_carve_golden(pb3d_gpu, golden):
+    g = golden("f2_carve")
+    for i in range(int(g["n"])):
+        out = pb3d_gpu.carve_voxel_grid_with_masks(g[f"grid_{i}"], g[f"mask_{i}"])
+        assert out.dtype == np.uint8 and out.shape == g[f"out_{i}"].shape and np.array_equal(out, g[f"out_{i}"]), i
+
+
+def test_rotate_step_golden_scipy(pb3d_gpu, golden):
+    """single affine_transform steps against SciPy's own outputs (no carve: mask=None)."""
+    import ctypes as C
+    lib, L = pb3d_gpu._lib.load(), pb3d_gpu._lib
+    g = golden("f3_affine")
+    for i in range(int(g["n"])):
+        x = np.ascontiguousarray(g[f"in_{i}"]); a = int(g[f"angle_{i}"])
+        W, H, D = x.shape
+        M = np.empty(9); off = np.empty(3)
+        L.check(lib.pb3d_rotinv(a, L.p_dbl(M)))
+        L.check(lib.pb3d_offset(L.p_dbl(M), (C.c_int64 * 3)(W, H, D), L.p_dbl(off)))
+        out = np.empty_like(x)
+        L.check(lib.pb3d_rotate_carve(L.ctx(), L.p_u8(x), W, H, D, L.p_dbl(M), L.p_dbl(off), None, L.p_u8(out)))
+        assert np.array_equal(out, g[f"out_{i}"]), (i, x.shape, a, int((out != g[f"out_{i}"]).sum()))
+
+
+def test_process_golden(pb3d_gpu, golden):
+    g = golden("f3_process")
+    for i in range(int(g["n"])):
+        out = pb3d_gpu.process_voxel_grid(g[f"grid_{i}"], g[f"mask_{i}"], int(g[f"ai_{i}"]))
+        want = g[f"out_{i}"]
+        assert np.array_equal(out, want), (i, want.shape, int(g[f"ai_{i}"]), int((out != want).sum()))
+
+
+@pytest.mark.parametrize("name", ["f4_Akbar_64", "f4_Bibi_64", "f4_Taj_96"])
+def test_real_masks_golden(pb3d_gpu, golden, name):
+    g = golden(name)
+    gc = pb3d_gpu.global_carve(g["binary"], g["ext"], angle_interval=90)
+    assert gc.shape == g["global_carve"].shape and np.array_equal(gc, g["global_carve"])
+    assert np.array_equal(pb3d_gpu.global_carve(g["binary"], g["ext"], angle_interval=45), g["global_carve_45"])
+    assert np.array_equal(pb3d_gpu.part_carve(gc, g["ext"], JOBS_NB1), g["part_carve_nb1"])
+    assert np.array_equal(pb3d_gpu.part_carve(gc, g["ext"], JOBS_MIXED), g["part_carve_mixed"])
+    from pb3d.voxel_carving_utils import _occupancy
+    assert np.array_equal(_occupancy(gc), np.any(g["global_carve"] > 0, -1).astype(np.uint8))
+
+
+def test_square_mask_double_transpose_golden(pb3d_gpu, golden):
+    g = golden("f4_square_64")
+    gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90)
+    assert np.array_equal(gc, g["global_carve"])
+    assert np.array_equal(pb3d_gpu.part_carve(gc, g["ext"], JOBS_NB1), g["part_carve_nb1"])
+
+
+@pytest.mark.parametrize("key", ["Akbar_128", "Bibi_128", "Taj_256"])
+def test_digests_configs_1_and_2(pb3d_gpu, golden, key):
+    """BASELINE configs[0] (Bibi front mask, 128^3) and configs[1] (Taj front mask, 256^3)."""
+    d = json.load(open(os.path.join(GOLDEN, "f4_digests.json")))[key]
+    g = golden(f"f4_{key}_masks")
+    gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90)
+    assert list(gc.shape) == d["shape"] and sha(gc) == d["global_carve_sha256"]
+    assert sha(pb3d_gpu.part_carve(gc, g["ext"], JOBS_NB1)) == d["part_carve_nb1_sha256"]
+
+
+def test_results1_taj512_pinned_parts(pb3d_gpu, golden):
+    """bit-exact with results/1.Orthographic_Voxel_Carving (Taj, 512): the parts the 90-degree path pins."""
+    g = golden("f9_Taj_512_masks")
+    stored = np.load(os.path.join(GOLDEN, "stored_Taj_voxel_grid.npz"))["voxel_grid"]
+    gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90)
+    pc = pb3d_gpu.part_carve(gc, g["ext"], JOBS_NB1)
+    oriented = np.flip(pc.transpose(2, 1, 0, 3), axis=1)
+    PC = pb3d_gpu.PART_COLORS
+    eq = lambda grid, name: np.all(grid == np.array(PC[name], np.uint8), axis=-1)
+    for part in ("plinth", "chhatris"):
+        assert np.array_equal(eq(oriented, part), eq(stored, part)), part
+    body = lambda grid: eq(grid, "full_building") | eq(grid, "main_door") | eq(grid, "windows")
+    assert np.array_equal(body(oriented), body(stored))
+
+
+def test_points_golden(pb3d_gpu, golden):
+    grid = np.load(os.path.join(GOLDEN, "stored_Akbar_voxel_grid.npz"))["voxel_grid"]
+    meta = json.load(open(os.path.join(GOLDEN, "f6_points_akbar.json")))
+    PC = pb3d_gpu.PART_COLORS
+    for key, m in meta.items():
+        kind, arg = key.split(":")
+        if kind == "parts":
+            p, c = pb3d_gpu.get_voxel_points_by_parts(grid, PC, arg.split(","))
+        else:
+            p, c, shp = pb3d_gpu.voxel_grid_to_points(grid, stride=int(arg))
+            assert list(shp) == m["shape"]
+        assert p.dtype == np.float32 and c.dtype == np.uint8 and len(p) == m["n"], key
+        assert sha(p) == m["pts_sha256"] and sha(c) == m["cols_sha256"], key
+
+
+def _cams(mon):
+    cams = json.load(open(os.path.join(GOLDEN, f"stored_{mon}_camera_params_final.json")))
+    conv = lambda o: np.array(o, np.float32) if isinstance(o, list) else ({k: conv(v) for k, v in o.items()} if isinstance(o, dict) else o)
+    return conv(cams)
+
+
+@pytest.mark.parametrize("mon", ["Akbar", "Charminar"])
+def test_projection_and_iou_golden(pb3d_gpu, golden, mon):
+    """config 3 as the reference implements it: stored grid -> points -> pinhole projection with the stored
+    front and aerial cameras -> per-part IoU."""
+    g = golden("f7_projection")
+    summ = json.load(open(os.path.join(GOLDEN, "f7_projection_summary.json")))
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = pb3d_gpu.PART_COLORS
+    pts, col = pb3d_gpu.get_voxel_points_by_parts(grid, PC, list(PC))
+    cams = _cams(mon)
+    for view in ("front", "drone"):
+        img = g[f"img_{mon}_{view}"]
+        for mode in ("f32", "f64"):
+            key = f"{mon}_{view}_{mode}"
+            s = summ[key]
+            cp, tg = cams[view]["cam_pos"], cams[view]["target"]
+            if mode == "f64":
+                cp, tg = cp.astype(np.float64), tg.astype(np.float64)
+            proj = pb3d_gpu.project_colored_voxels(pts, col, cp, tg, cams[view]["f"], cams[view]["cx"], cams[view]["cy"], s["H"], s["W"])
+            assert np.array_equal(proj, g[f"proj_{key}"]), (key, int((proj != g[f"proj_{key}"]).any(-1).sum()))
+            per, mean = pb3d_gpu.compute_partwise_iou(proj, img, PC)
+            assert {k: float(v) for k, v in per.items()} == s["iou"] and float(mean) == s["mean"]
+
+
+def test_projection_synth_modes_golden(pb3d_gpu, golden):
+    g = golden("f7_projection_synth")
+    tmap = {"float": float, "float64": np.float64, "float32": np.float32}
+    for i in range(int(g["n"])):
+        f, cx, cy = (tmap[t](v) for t, v in zip(g[f"ftypes_{i}"], g[f"fcxcy_{i}"]))
+        H, W = (int(v) for v in g[f"hw_{i}"])
+        out = pb3d_gpu.project_colored_voxels(g[f"pts_{i}"], g[f"cols_{i}"], g[f"cam_{i}"], g[f"tgt_{i}"], f, cx, cy, H, W)
+        assert np.array_equal(out, g[f"out_{i}"]), (i, int((out != g[f"out_{i}"]).any(-1).sum()))
+
+
+# ---- seeded inputs against the oracle -----------------------------------------------------------------
+def test_carve_vs_oracle_shapes(pb3d_gpu, oracle):
+    rng = np.random.default_rng(7)
+    shapes = [(1, 1, 1), (3, 2, 5), (17, 9, 16), (8, 5, 48), (64, 64, 64), (5, 7, 1024), (33, 31, 100), (2, 130, 16),
+              (40, 3, 1040), (9, 9, 2741)]
+    for (W, H, D) in shapes:
+        for nd in (3, 4):
+            grid = rng.integers(0, 256, (W, H, D) + ((3,) if nd == 4 else ()), dtype=np.uint8)
+            for frac in (0.0, 0.5, 1.0):
+                m = rng.random((H, W)) < frac
+                assert np.array_equal(pb3d_gpu.carve_voxel_grid_with_masks(grid, m), oracle.carve_voxel_grid_with_masks(grid, m)), (W, H, D, nd, frac)
+    # empty grids
+    for shp in [(0, 4, 4), (4, 0, 4), (4, 4, 0)]:
+        e = np.zeros(shp, np.uint8)
+        out = pb3d_gpu.carve_voxel_grid_with_masks(e, np.ones((shp[1], shp[0]), bool) if shp[0] != shp[1] else np.ones((shp[0], shp[1]), bool))
+        assert out.shape == shp
+
+
+def test_process_vs_oracle_angles(pb3d_gpu, oracle):
+    rng = np.random.default_rng(11)
+    for (W, H, D) in [(31, 6, 31), (40, 5, 28), (7, 3, 50), (96, 4, 96), (1, 2, 1), (130, 2, 260)]:
+        for kind in ("bin", "full"):
+            g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "bin" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+            m = rng.random((H, W)) < 0.9
+            for ai in (90, 45, 30, 10, 7, 1 if W < 40 else 15, 91, 200):
+                got = pb3d_gpu.process_voxel_grid(g, m, ai)
+                want = oracle.process_voxel_grid(g, m, ai)
+                assert np.array_equal(got, want), (W, H, D, kind, ai, int((got != want).sum()))
+
+
+def test_color_apply_and_occupancy_vs_oracle(pb3d_gpu, oracle):
+    rng = np.random.default_rng(13)
+    from pb3d.voxel_carving_utils import _occupancy
+    for (W, H, D) in [(16, 9, 16), (5, 4, 7), (32, 3, 64), (3, 3, 33)]:
+        carved = rng.integers(0, 3, (W, H, D), dtype=np.uint8)  # values 0,1,2: only == 1 is coloured
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        assert np.array_equal(pb3d_gpu.apply_colored_mask_to_voxel_grid(carved, rgb), oracle.apply_colored_mask_to_voxel_grid(carved, rgb))
+        grid = rng.integers(0, 2, (W, H, D, 3), dtype=np.uint8) * rng.integers(0, 256, (W, H, D, 3), dtype=np.uint8)
+        assert np.array_equal(_occupancy(grid), oracle.occupancy(grid))
+
+
+def test_part_carve_vs_oracle_foreign_colours(pb3d_gpu, oracle, golden):
+    """grids that hold colours the mask does not (kept by global_carve, dropped by part_carve)."""
+    rng = np.random.default_rng(17)
+    g = golden("f4_Bibi_64")
+    colored = g["global_carve"].copy()
+    k = rng.random(colored.shape[:3]) < 0.1
+    colored[k] = rng.integers(0, 256, (int(k.sum()), 3), dtype=np.uint8)
+    for jobs in (JOBS_NB1, JOBS_MIXED, [], [(["windows"], 90)]):
+        assert np.array_equal(pb3d_gpu.part_carve(colored, g["ext"], jobs), oracle.part_carve(colored, g["ext"], jobs)), jobs
+
+
+def test_points_vs_oracle(pb3d_gpu, oracle):
+    rng = np.random.default_rng(19)
+    pal = np.array(list(oracle.PART_COLORS.values()) + [(0, 0, 0)], np.uint8)
+    for shp in [(1, 1, 1), (9, 7, 11), (40, 33, 29), (5, 3, 4200), (130, 2, 3)]:
+        grid = pal[rng.integers(0, len(pal), shp)]
+        for names in (["dome"], ["plinth", "windows", "background"], list(oracle.PART_COLORS)):
+            gp, gc = pb3d_gpu.get_voxel_points_by_parts(grid, oracle.PART_COLORS, names)
+            op, oc = oracle.get_voxel_points_by_parts(grid, oracle.PART_COLORS, names)
+            assert np.array_equal(gp, op) and np.array_equal(gc, oc), (shp, names)
+        for st in (1, 2, 3, 5):
+            gp, gc, gs = pb3d_gpu.voxel_grid_to_points(grid, stride=st)
+            op, oc, os_ = oracle.voxel_grid_to_points(grid, stride=st)
+            assert np.array_equal(gp, op) and np.array_equal(gc, oc) and gs == os_, (shp, st)
+    # all-empty and all-full
+    z = np.zeros((6, 5, 4, 3), np.uint8)
+    p, c, _ = pb3d_gpu.voxel_grid_to_points(z, stride=1)
+    assert p.shape == (0, 3) and c.shape == (0, 3)
+    p, c, _ = pb3d_gpu.voxel_grid_to_points(z + 9, stride=1)
+    assert len(p) == 120 and np.array_equal(p[1], [1, 0, 0])
+
+
+def test_projection_duplicates_last_writer_wins(pb3d_gpu, oracle):
+    """many points on one pixel: the last in input order must win, run after run."""
+    rng = np.random.default_rng(23)
+    N = 200000
+    pts = rng.integers(0, 8, (N, 3)).astype(np.float32)      # only 512 distinct positions -> massive collisions
+    cols = rng.integers(1, 256, (N, 3), dtype=np.uint8)
+    cam = np.array([4, 4, -30], np.float32); tgt = np.array([4, 4, 4], np.float32)
+    want = oracle.project_colored_voxels(pts, cols, cam, tgt, 100.0, 32.0, 32.0, 64, 64)
+    for _ in range(3):
+        got = pb3d_gpu.project_colored_voxels(pts, cols, cam, tgt, 100.0, 32.0, 32.0, 64, 64)
+        assert np.array_equal(got, want)
+    # no points at all -> black image
+    e = pb3d_gpu.project_colored_voxels(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), cam, tgt, 100.0, 32.0, 32.0, 8, 8)
+    assert e.shape == (8, 8, 3) and not e.any()
+
+
+# ---- full-size properties (BASELINE config 4: synthetic 16-label mask, 1024^3) -----------------------
+def test_full_size_carve_properties(pb3d_gpu):
+    """1024^3 semantic carve (6.4 GB of traffic) checked through size-independent properties:
+    idempotence, per-plane byte sums equal to the masked input sums, dropped columns all zero, and a slab
+    of the volume bit-equal to NumPy's np.where on the same bytes."""
+    import synth_host
+    from pb3d import device as dev
+    S = int(os.environ.get("PB3D_TEST_FULL_SIZE", "1024"))
+    nvox = S * S * S
+    d_in = dev.DeviceBuffer(nvox * 3); d_out = dev.DeviceBuffer(nvox * 3); d_out2 = dev.DeviceBuffer(nvox * 3)
+    d_mwh = dev.DeviceBuffer(S * S)
+    dev.synth_sem(0, S, S, S, 1, d_in)
+    dev.synth_mask16(S, d_binary_wh=d_mwh)
+    dev.carve_mask(d_in, S, S, S, 3, d_mwh, d_out)
+    dev.carve_mask(d_out, S, S, S, 3, d_mwh, d_out2)       # idempotence
+    dev.sync()
+    lab, binary, rgb = synth_host.mask16(S)
+    m_wh = np.ascontiguousarray(binary.T)
+    assert np.array_equal(d_mwh.download((S, S)), m_wh)
+    step = max(1, S // 8)
+    planes = 2
+    for x0 in list(range(0, S, step)) + [S - planes]:
+        off = x0 * S * S * 3
+        a = d_in.download((planes, S, S, 3), byte_offset=off)
+        b = d_out.download((planes, S, S, 3), byte_offset=off)
+        c = d_out2.download((planes, S, S, 3), byte_offset=off)
+        assert np.array_equal(a, synth_host.sem_slab(x0, x0 + planes, S, S, 1))            # device generator == host formula
+        want = np.where(m_wh[x0:x0 + planes, :, None, None].astype(bool), a, 0).astype(np.uint8)
+        assert np.array_equal(b, want) and np.array_equal(c, b)
+        assert int(b.astype(np.uint64).sum()) == int(a[m_wh[x0:x0 + planes].astype(bool)].astype(np.uint64).sum())
+    for buf in (d_in, d_out, d_out2, d_mwh):
+        buf.free()

@@ -1,0 +1,94 @@
+"""CPU-only: host-side logic of the shim that mirrors reference behaviour without touching the GPU."""
+import numpy as np
+import pytest
+
+
+def test_mask_to_wh_rule():
+    from pb3d.voxel_carving_utils import _mask_to_wh
+    m = np.arange(12).reshape(3, 4)
+    assert _mask_to_wh(m, 4, 3).shape == (4, 3) and np.array_equal(_mask_to_wh(m, 4, 3), m.T)   # (H,W) -> .T
+    assert _mask_to_wh(m, 3, 4) is not None and np.array_equal(_mask_to_wh(m, 3, 4), m)       # already (W,H)
+    sq = np.arange(9).reshape(3, 3)
+    assert np.array_equal(_mask_to_wh(sq, 3, 3), sq.T)   # square: the (H,W) test wins -> always transposed
+    with pytest.raises(ValueError, match=r"Mask shape \(3, 4\) incompatible with \(W,H\)=\(5,4\)"):
+        _mask_to_wh(m, 5, 4)
+
+
+def test_argument_errors_before_any_device_work():
+    import pb3d
+    g = np.zeros((4, 3, 2), np.uint8)
+    with pytest.raises(ValueError, match="incompatible"):
+        pb3d.carve_voxel_grid_with_masks(g, np.ones((5, 5), bool))
+    with pytest.raises(ValueError, match="incompatible"):
+        pb3d.process_voxel_grid(g, np.ones((5, 5), bool), 90)
+    with pytest.raises(TypeError):
+        pb3d.process_voxel_grid(g, np.ones((3, 4), bool), 45.0)
+    with pytest.raises(ValueError, match="must not be zero"):
+        pb3d.process_voxel_grid(g, np.ones((3, 4), bool), 0)
+    with pytest.raises(TypeError, match="uint8"):
+        pb3d.carve_voxel_grid_with_masks(g.astype(np.float32), np.ones((3, 4), bool))
+    with pytest.raises(ValueError, match="broadcast"):
+        pb3d.carve_voxel_grid_with_masks(np.zeros((4, 3, 2, 3), np.uint8), np.ones((4, 3, 3), np.uint8))
+    # negative step: range(0, 91, -5) is empty and upstream returns the grid unchanged
+    assert np.array_equal(pb3d.process_voxel_grid(g + 1, np.ones((3, 4), bool), -5), g + 1)
+    # empty part list -> empty outputs without touching the device
+    p, c = pb3d.get_voxel_points_by_parts(np.zeros((2, 2, 2, 3), np.uint8), pb3d.PART_COLORS, [])
+    assert p.shape == (0, 3) and p.dtype == np.float32 and c.shape == (0, 3) and c.dtype == np.uint8
+
+
+def test_look_at_matches_golden(golden):
+    import json
+    import os
+    from conftest import GOLDEN
+    from pb3d.camera_geometry import look_at_rotation
+    g = golden("f7_projection")
+    for mon in ("Akbar", "Charminar"):
+        cams = json.load(open(os.path.join(GOLDEN, f"stored_{mon}_camera_params_final.json")))
+        for view in ("front", "drone"):
+            for mode, dt in (("f32", np.float32), ("f64", np.float64)):
+                cp = np.array(cams[view]["cam_pos"], np.float32).astype(dt)
+                tg = np.array(cams[view]["target"], np.float32).astype(dt)
+                R = look_at_rotation(cp, tg)
+                assert R.dtype == dt and np.array_equal(R, g[f"R_{mon}_{view}_{mode}"])
+    # degenerate view direction (looking straight along +Y) switches the up vector
+    R = look_at_rotation(np.zeros(3, np.float32), np.array([0, 5, 0], np.float32))
+    assert np.array_equal(R[2], [0, 1, 0]) and np.all(np.isfinite(R))
+
+
+def test_promotion_flags():
+    from pb3d.projection_utils import _promotes_to_f64
+    assert not _promotes_to_f64(1.5) and not _promotes_to_f64(3)
+    assert _promotes_to_f64(np.float64(1.5)) and not _promotes_to_f64(np.float32(1.5))
+    assert _promotes_to_f64(np.array(2.0)) and _promotes_to_f64(np.int64(3)) and not _promotes_to_f64(np.int16(3))
+
+
+def test_slab_bounds_cover_and_balance():
+    from pb3d.dist import equal_slabs, slab_bounds
+    for n in (1, 7, 8, 1024, 1023, 355):
+        for r in (1, 2, 3, 4, 8):
+            b = [slab_bounds(n, k, r) for k in range(r)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[k][1] == b[k + 1][0] for k in range(r - 1))
+            sizes = [x1 - x0 for x0, x1 in b]
+            assert max(sizes) - min(sizes) <= 1
+    assert equal_slabs(1024, 8) == 128
+    with pytest.raises(ValueError):
+        equal_slabs(1023, 8)
+    with pytest.raises(ValueError):
+        slab_bounds(8, 8, 8)
+
+
+def test_install_patches_a_utils_like_package():
+    import sys
+    import types
+    import pb3d
+    pkg = types.ModuleType("fakeutils"); sub = types.ModuleType("fakeutils.voxel_carving_utils")
+    sub.process_voxel_grid = lambda *a: "old"; sub.left_right_guided_carve = lambda *a: "kept"
+    pkg.process_voxel_grid = sub.process_voxel_grid
+    sys.modules["fakeutils"] = pkg; sys.modules["fakeutils.voxel_carving_utils"] = sub
+    try:
+        patched = pb3d.install(pkg)
+        assert ("fakeutils.voxel_carving_utils", "process_voxel_grid") in patched and ("fakeutils", "process_voxel_grid") in patched
+        assert sub.process_voxel_grid is pb3d.process_voxel_grid and sub.left_right_guided_carve() == "kept"
+    finally:
+        del sys.modules["fakeutils"], sys.modules["fakeutils.voxel_carving_utils"]
