@@ -14,54 +14,51 @@ __device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { __builtin_nontemporal
 
 // ------------------------------------------------------------------------------------------------
 // K1 fast path: column size col = D*C is a multiple of 16 bytes, buffers 16-byte aligned.
-// One wavefront owns a tile of 64 consecutive columns: lane l reads mask byte l of the tile,
-// a wave64 ballot turns the 64 keep/drop decisions into one 64-bit scalar word, and the wave
-// then sweeps the tile's 64*vpc 16-byte vectors.  Dropped columns are never read -- their
-// lanes are predicated off (wave-uniformly when vpc % 64 == 0) and only zeros are stored.
+// One workgroup (512 threads) per voxel tile of kTileVec = 768 consecutive 16-byte vectors (12 KiB:
+// 4 columns of a 1024^3 RGB grid).  The slice of the 2-D mask the tile touches is staged in LDS;
+// each lane looks up its column's keep byte and a wave64 ballot turns the 64 decisions into one
+// scalar word: all-drop wavefronts issue no load at all, all-keep wavefronts load unpredicated.
+// Dropped columns are never read -- only zeros are stored.  Many small tiles and at most two loads
+// per lane measured fastest on MI355X (profiles/r01_k1_variants.md): the hardware dispatcher
+// balances the stream better than a persistent grid-stride loop.
 // ------------------------------------------------------------------------------------------------
-template <bool UNIFORM>
-__global__ __launch_bounds__(256) void k_carve_cols(const u32x4* __restrict__ in, u32x4* __restrict__ out,
-                                                    const u8* __restrict__ mask, i64 ncols, u32 vpc, u32 magic,
-                                                    i64 ntiles) {
-    const u32 lane = threadIdx.x & 63;
-    // wave index made provably wave-uniform so tile bounds and the keep test live in SGPRs
-    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);
-    for (i64 t = wave; t < ntiles; t += nwaves) {
-        const i64 col0 = t * 64;
-        const i64 c_here = ncols - col0 < 64 ? ncols - col0 : 64;
-        const u8 m = (i64)lane < c_here ? mask[col0 + lane] : (u8)0;
-        const u64 kbits = __ballot(m != 0);
-        const u32 nvec = (u32)c_here * vpc;
-        const u32x4* src = in + col0 * vpc;
-        u32x4* dst = out + col0 * vpc;
-        for (u32 v0 = 0; v0 < nvec; v0 += 256) {
-            u32x4 x[4];
+constexpr int kTileVec = 768;
+constexpr int kTileThreads = 512;
+constexpr int kTileMaskMax = kTileVec + 2;  // vpc == 1 -> one column per vector (+ straddle)
+
+__global__ __launch_bounds__(kTileThreads) void k_carve_tiles(const u32x4* __restrict__ in, u32x4* __restrict__ out,
+                                                              const u8* __restrict__ mask, i64 nvec, i64 ncols, u32 vpc,
+                                                              u32 magic) {
+    __shared__ u8 smask[kTileMaskMax];
+    const i64 v_begin = (i64)blockIdx.x * kTileVec;
+    const i64 first_col = v_begin / vpc;                       // block-uniform (scalar unit)
+    const u32 rem0 = (u32)(v_begin - first_col * vpc);
+    const i64 left = nvec - v_begin;
+    const u32 n_here = left < kTileVec ? (u32)left : (u32)kTileVec;
+    const u32 ncol_here = (rem0 + n_here + vpc - 1) / vpc;
+    for (u32 c = threadIdx.x; c < ncol_here; c += kTileThreads) smask[c] = first_col + c < ncols ? mask[first_col + c] : (u8)0;
+    __syncthreads();
+    const u32x4* src = in + v_begin;
+    u32x4* dst = out + v_begin;
+    u32x4 x[2];
+    bool live[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const u32 vv = v0 + 64 * u + lane;
-                x[u] = (u32x4)(0u);
-                if (UNIFORM) {
-                    // vpc % 64 == 0: the 64 lanes of this step sit in one column -> scalar decision
-                    const u32 vs = v0 + 64 * u;
-                    if (vs < nvec) {
-                        const u32 c = __umulhi(vs, magic);
-                        if ((kbits >> c) & 1) x[u] = ld_nt(src + vv);
-                    }
-                } else {
-                    if (vv < nvec) {
-                        const u32 c = magic ? __umulhi(vv, magic) : vv / vpc;
-                        if ((kbits >> c) & 1) x[u] = ld_nt(src + vv);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const u32 vv = v0 + 64 * u + lane;
-                if (vv < nvec) st_nt(dst + vv, x[u]);
-            }
+    for (int u = 0; u < 2; ++u) {
+        const u32 lv = threadIdx.x + kTileThreads * u;
+        live[u] = lv < n_here;
+        x[u] = (u32x4)(0u);
+        bool keep = false;
+        if (live[u]) {
+            const u32 q = rem0 + lv;
+            keep = smask[magic ? __umulhi(q, magic) : q / vpc] != 0;
         }
+        const u64 kb = __ballot(keep);
+        if (kb == ~0ull) x[u] = ld_nt(src + lv);               // whole wavefront keeps: unpredicated 1 KiB load
+        else if (kb != 0 && keep) x[u] = ld_nt(src + lv);      // mixed wavefront (column boundary inside it)
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (live[u]) st_nt(dst + threadIdx.x + kTileThreads * u, x[u]);
 }
 
 // K1 generic path: any column size / alignment; one thread per byte run of 16 (slow, rarely used:
@@ -223,22 +220,17 @@ int pb3d_carve_mask_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t W, int64_t
     if (nbytes == 0) return PB3D_OK;
     PB3D_REQUIRE(d_grid && d_mask_wh && d_out, "pb3d_carve_mask: null buffer");
     PB3D_REQUIRE(d_grid != d_out, "pb3d_carve_mask: in-place carve is not supported");
-    const bool fast = (col % 16 == 0) && aligned16(d_grid) && aligned16(d_out) && (col / 16) < (1u << 25);
+    const bool fast = (col % 16 == 0) && aligned16(d_grid) && aligned16(d_out) && (nbytes / 16) / kTileVec < (1ll << 31);
     if (fast) {
-        const u32 vpc = (u32)(col / 16);
-        // c = vv / vpc for vv < 64*vpc through one umulhi: exact while 64*vpc*vpc < 2^32
+        const i64 nvec = nbytes / 16;
+        const u32 vpc = (u32)(col / 16 < (1ll << 31) ? col / 16 : 0);
+        PB3D_REQUIRE(vpc != 0, "pb3d_carve_mask: column too long");
+        // (rem0 + lv) / vpc with rem0 + lv < vpc + 768 through one umulhi: exact while (vpc + 768) * vpc < 2^32
         u32 magic = 0;
-        if (vpc == 1) magic = 0;  // handled by the division path (vv / 1)
-        else if ((u64)64 * vpc * vpc < (1ull << 32)) magic = (u32)(((1ull << 32) + vpc - 1) / vpc);
-        const i64 ntiles = (ncols + 63) / 64;
-        const unsigned blocks = pb3d_stream_blocks(ctx, ntiles, 4, 8);
-        const bool uniform = (vpc % 64 == 0) && magic != 0;
-        if (uniform)
-            hipLaunchKernelGGL(k_carve_cols<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)d_grid,
-                               (u32x4*)d_out, d_mask_wh, ncols, vpc, magic, ntiles);
-        else
-            hipLaunchKernelGGL(k_carve_cols<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)d_grid,
-                               (u32x4*)d_out, d_mask_wh, ncols, vpc, magic, ntiles);
+        if (vpc > 1 && ((u64)vpc + kTileVec) * vpc < (1ull << 32)) magic = (u32)(((1ull << 32) + vpc - 1) / vpc);
+        const unsigned blocks = (unsigned)((nvec + kTileVec - 1) / kTileVec);
+        hipLaunchKernelGGL(k_carve_tiles, dim3(blocks), dim3(kTileThreads), 0, ctx->stream, (const u32x4*)d_grid,
+                           (u32x4*)d_out, d_mask_wh, nvec, ncols, vpc, magic);
     } else {
         const unsigned blocks = pb3d_stream_blocks(ctx, (nbytes + 15) / 16, 256, 8);
         hipLaunchKernelGGL(k_carve_bytes, dim3(blocks), dim3(256), 0, ctx->stream, d_grid, d_out, d_mask_wh, nbytes, col);

@@ -1,0 +1,47 @@
+"""Summarise rocprofv3 PMC passes into profiles/pmc_traffic.json (read by bench.py for roofline.traffic).
+
+Usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <voxels_per_launch> [tag]
+
+Per MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE --pmc passes
+(TCC slots), both are reported in KiB, WRITE_SIZE is exact for 16-byte-per-lane streaming stores and on
+gfx950 FETCH_SIZE reads exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled.
+"""
+import csv
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            name = r["Kernel_Name"].split("(")[0].split("::")[-1]
+            out.setdefault(name, []).append(float(r["Counter_Value"]))
+    return {k: statistics.median(v) for k, v in out.items()}
+
+
+def main():
+    fetch_csv, write_csv, nvox = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    tag = sys.argv[4] if len(sys.argv) > 4 else ""
+    fetch = per_kernel(fetch_csv, "FETCH_SIZE")
+    write = per_kernel(write_csv, "WRITE_SIZE")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    recs = json.load(open(path)) if os.path.exists(path) else []
+    for k in sorted(set(fetch) & set(write)):
+        if k.startswith("k_synth"):
+            continue
+        rd = fetch[k] * 1024 * 2      # KiB -> bytes, gfx950 wide-read correction x2
+        wr = write[k] * 1024          # KiB -> bytes, exact
+        rec = {"kernel": k, "voxels_per_launch": nvox, "fetch_size_kib_raw": fetch[k], "write_size_kib_raw": write[k],
+               "read_bytes_corrected": int(rd), "write_bytes": int(wr), "hbm_bytes_per_launch": int(rd + wr), "tag": tag}
+        recs = [r for r in recs if not (r["kernel"] == k and r["voxels_per_launch"] == nvox)] + [rec]
+        print(rec)
+    json.dump(recs, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
