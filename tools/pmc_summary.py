@@ -9,6 +9,7 @@ gfx950 FETCH_SIZE reads exactly half of the bytes of a wide (16 B/lane) coalesce
 import csv
 import json
 import os
+import re
 import statistics
 import sys
 
@@ -19,7 +20,8 @@ def per_kernel(path, counter):
     out = {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            name = r["Kernel_Name"].split("(")[0].split("::")[-1]
+            m = re.search(r"\b(k_\w+)", r["Kernel_Name"])
+            name = m.group(1) if m else r["Kernel_Name"]
             out.setdefault(name, []).append(float(r["Counter_Value"]))
     return {k: statistics.median(v) for k, v in out.items()}
 
