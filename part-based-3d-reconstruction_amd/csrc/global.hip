@@ -24,6 +24,14 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     const i64 W = w, H = h, D = w, nvox = W * H * D;
     if (nvox == 0 || x1 == x0) return PB3D_OK;
     PB3D_REQUIRE(d_bin_hw && d_rgb_hw3 && d_out_slab, "pb3d_global_carve: null buffer");
+    if (angle_interval == 90 && W <= 4096) {
+        // angles [0, 90]: both steps are exact permutations on a (w,h,w) grid -> one write-only kernel
+        const i64 shape[3] = {W, H, D};
+        double M[9], off[3];
+        PB3D_TRY(pb3d_rotinv(90, M));
+        PB3D_TRY(pb3d_offset(M, shape, off));
+        if (pb3d_is_perm_step(M, off, W, D)) return pb3d_launch_global_carve90(ctx, d_bin_hw, d_rgb_hw3, h, w, M, off, x0, x1, d_out_slab);
+    }
     // generic pipeline on the full occupancy grid (rotation mixes x), colour only the slab
     void *ones, *carved, *tmp, *mwh;
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &ones));

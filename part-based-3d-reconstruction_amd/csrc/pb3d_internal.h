@@ -14,7 +14,7 @@ typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-#define PB3D_NSCRATCH 10
+#define PB3D_NSCRATCH 16
 
 struct pb3d_event {
     hipEvent_t ev;
@@ -38,7 +38,6 @@ struct pb3d_ctx {
         u8 colors[3 * 32];
         bool valid;
     } pts;
-    // cached per-(x,z) source tables of permutation-like rotation steps
     // RCCL (loaded lazily with dlopen; see comm.hip)
     void* rccl_lib;
     void* rccl_comm;
@@ -84,13 +83,11 @@ static inline unsigned pb3d_stream_blocks(const pb3d_ctx* ctx, i64 work_items, i
     return (unsigned)(need < cap ? need : cap);
 }
 
-// exact unsigned division by a runtime constant d (1 <= d < 2^31) for n < 2^32:
-// q = umulhi(n, m) >> s after an add-back; we keep it simple and exact with 64-bit math.
-struct pb3d_fastdiv {
-    u32 d;
-    u64 m;  // ceil(2^40 / d)  -> exact for n < 2^20 * ... (see fastdiv_make); fallback to '/' otherwise
-};
-
 // ---- kernels' host launchers used across translation units ---------------------------------
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
                                const double off[3], const u8* d_mask_wh, u8* d_out);
+bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D);
+int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
+                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out);
+int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, i64 h, i64 w, const double M[9],
+                               const double off[3], i64 x0, i64 x1, u8* d_out_slab);

@@ -141,6 +141,9 @@ int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     PB3D_REQUIRE(W >= 0 && H >= 0 && D >= 0, "pb3d_rotate_carve: bad shape");
     if (W * H * D == 0) return PB3D_OK;
     PB3D_REQUIRE(d_occ && d_out && d_occ != d_out, "pb3d_rotate_carve: null or aliased buffer");
+    const bool row1 = M[3] == 0.0 && M[4] == 1.0 && M[5] == 0.0 && M[1] == 0.0 && M[7] == 0.0 && off[1] == 0.0;
+    if (row1 && pb3d_is_perm_step(M, off, W, D) && D % 4 == 0 && (((uintptr_t)d_occ | (uintptr_t)d_out) & 3u) == 0)
+        return pb3d_launch_rotate_perm(ctx, d_occ, W, H, D, M, off, nullptr, d_mask_wh, d_out);
     return pb3d_launch_rotate_generic(ctx, d_occ, W, H, D, M, off, d_mask_wh, d_out);
 }
 
@@ -155,22 +158,36 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     PB3D_REQUIRE(d_out != d_occ && d_tmp != d_occ && d_tmp != d_out, "pb3d_process_grid: buffers must not alias");
     const int nsteps = 90 / angle_interval + 1;  // len(range(0, 91, k))
     const i64 shape[3] = {W, H, D};
-    // ping-pong so that the last step lands in d_out
+    // Step 0 is Rinv(0) = I with zero offset: coordinates are the integers themselves, weights {1,0},
+    // acc == v and (uint8)(v + 0.5) == v, i.e. the step is the mask carve alone.
+    double M0[9], off0[3];
+    PB3D_TRY(pb3d_rotinv(0, M0));
+    PB3D_TRY(pb3d_offset(M0, shape, off0));
+    bool ident = off0[0] == 0.0 && off0[1] == 0.0 && off0[2] == 0.0;
+    for (int k = 0; k < 9; ++k) ident = ident && M0[k] == ((k % 4 == 0) ? 1.0 : 0.0);
+    PB3D_REQUIRE(ident, "pb3d_process_grid: internal error, Rinv(0) is not the identity");
+    if (nsteps == 1) return pb3d_carve_mask_dev(ctx, d_occ, W, H, D, 1, d_mask_wh, d_out);
+    double M1[9], off1[3];
+    PB3D_TRY(pb3d_rotinv(angle_interval, M1));
+    PB3D_TRY(pb3d_offset(M1, shape, off1));
+    // A permutation-like second step (90 degrees, W + D even) takes the 0-degree carve as its source mask.
+    const bool fuse_first = pb3d_is_perm_step(M1, off1, W, D) && D % 4 == 0 &&
+                            (((uintptr_t)d_occ | (uintptr_t)d_out | (uintptr_t)d_tmp) & 3u) == 0;
+    const int nlaunch = fuse_first ? nsteps - 1 : nsteps;
     const u8* src = d_occ;
-    for (int s = 0; s < nsteps; ++s) {
-        const int angle = s * angle_interval;
-        double M[9], off[3];
-        PB3D_TRY(pb3d_rotinv(angle, M));
-        PB3D_TRY(pb3d_offset(M, shape, off));
-        u8* dst = ((nsteps - 1 - s) % 2 == 0) ? d_out : d_tmp;
-        bool ident = off[0] == 0.0 && off[1] == 0.0 && off[2] == 0.0;
-        for (int k = 0; k < 9; ++k) ident = ident && M[k] == ((k % 4 == 0) ? 1.0 : 0.0);
-        if (ident) {
-            // Rinv(0) is exactly I with zero offset: every coordinate is the integer itself, the
-            // weights are {1,0}, acc == v and (uint8)(v + 0.5) == v -- the step is the carve alone.
+    int li = 0;
+    for (int s = fuse_first ? 1 : 0; s < nsteps; ++s, ++li) {
+        u8* dst = ((nlaunch - 1 - li) % 2 == 0) ? d_out : d_tmp;  // ping-pong so that the last step lands in d_out
+        if (s == 0) {
             PB3D_TRY(pb3d_carve_mask_dev(ctx, src, W, H, D, 1, d_mask_wh, dst));
         } else {
-            PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst));
+            double M[9], off[3];
+            PB3D_TRY(pb3d_rotinv(s * angle_interval, M));
+            PB3D_TRY(pb3d_offset(M, shape, off));
+            if (pb3d_is_perm_step(M, off, W, D) && D % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3u) == 0)
+                PB3D_TRY(pb3d_launch_rotate_perm(ctx, src, W, H, D, M, off, (fuse_first && s == 1) ? d_mask_wh : nullptr, d_mask_wh, dst));
+            else
+                PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst));
         }
         src = dst;
     }

@@ -1,0 +1,410 @@
+// K2': rotation steps whose coordinates are (numerically almost) integers -- 0 and 90 degrees on
+// grids with W + D even -- as LDS-tiled byte permutations, and K4: the fused global_carve.
+//
+// For such a step every source coordinate cc lies within 2^-18 of an integer, so SciPy's trilinear
+// sum has one weight >= 1 - 2^-17 and the rest <= 2^-18; with uint8 data |acc - v_nearest| < 0.01, the
+// "+0.5, truncate" store returns v_nearest exactly, and acc > 0 iff it should (proof in DESIGN.md).
+// The border decisions (cc < 0, cc > n-1) are still taken on the SAME f64 values SciPy computes --
+// cos(90 deg) = 6.1e-17 drops ~1 % of the border cells and that is reproduced, not patterned.
+// The kernel is then a tiled transpose inside each Y-plane: the source tile is staged through LDS
+// with coalesced dword row loads, outputs are gathered from LDS and stored as packed dwords.
+#include "pb3d_internal.h"
+
+namespace {
+
+struct RotParams {
+    double m00, m01, m02, off0;
+    double m20, m21, m22, off2;
+};
+
+__device__ __forceinline__ double coord(double x, double z, double ma, double mb, double mc, double off) {
+    double c = __dadd_rn(0.0, __dmul_rn(x, ma));
+    c = __dadd_rn(c, __dmul_rn(0.0, mb));
+    c = __dadd_rn(c, __dmul_rn(z, mc));
+    return __dadd_rn(c, off);
+}
+
+// nearest source voxel of output (x,z), or false when SciPy's bounds test rejects the coordinate
+__device__ __forceinline__ bool source_of(const RotParams& p, i64 x, i64 z, i64 W, i64 D, int* n0, int* n2) {
+    const double cc0 = coord((double)x, (double)z, p.m00, p.m01, p.m02, p.off0);
+    const double cc2 = coord((double)x, (double)z, p.m20, p.m21, p.m22, p.off2);
+    if (cc0 < 0.0 || cc0 > (double)(W - 1) || cc2 < 0.0 || cc2 > (double)(D - 1)) return false;
+    *n0 = (int)rint(cc0);
+    *n2 = (int)rint(cc2);
+    return true;
+}
+
+constexpr int T = 64;          // tile edge (voxels)
+constexpr int PITCH = T + 8;   // LDS row pitch in bytes (dword multiple; z start is aligned down to 4)
+constexpr int ROWS = T + 1;
+constexpr int MAXLD = (ROWS * (PITCH / 4) + 255) / 256;  // staging dwords per thread
+
+// out[x,y,z] = mask_dst[x,y] && valid(x,z) ? (mask_src[n0,y] ? in[n0,y,n2] : 0) : 0
+__global__ __launch_bounds__(256) void k_rotate_perm(const u8* __restrict__ in, u8* __restrict__ out,
+                                                     const u8* __restrict__ mask_src, const u8* __restrict__ mask_dst,
+                                                     RotParams p, i64 W, i64 H, i64 D, int TY) {
+    __shared__ __attribute__((aligned(16))) u8 tile[ROWS * PITCH];
+    __shared__ int bb[4];  // min n0, max n0, min n2, max n2
+    const int tid = threadIdx.x;
+    const i64 x0 = (i64)blockIdx.y * T, z0 = (i64)blockIdx.x * T;
+    const i64 y_beg = (i64)blockIdx.z * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+    __syncthreads();
+    // 16 cells per thread: rows xl = tid/16 + 16k (k = 0..3), z = (tid%16)*4 + q (q = 0..3)
+    const int zl = (tid & 15) * 4, xl0 = tid >> 4;
+    int n0[16], n2[16];
+    int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const i64 x = x0 + xl0 + 16 * k, z = z0 + zl + q;
+            int a = -1, b = -1;
+            if (x < W && z < D && source_of(p, x, z, W, D, &a, &b)) {
+                mn0 = a < mn0 ? a : mn0; mx0 = a > mx0 ? a : mx0;
+                mn2 = b < mn2 ? b : mn2; mx2 = b > mx2 ? b : mx2;
+            } else {
+                a = -1;
+            }
+            n0[4 * k + q] = a; n2[4 * k + q] = b;
+        }
+    if (mx0 >= 0) {
+        atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); atomicMin(&bb[2], mn2); atomicMax(&bb[3], mx2);
+    }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1], bz0 = bb[2] & ~3, bz1 = bb[3];
+    const bool any_valid = bx1 >= 0;
+    const int nrows = any_valid ? bx1 - bx0 + 1 : 0;
+    const int nd = any_valid ? (bz1 - bz0) / 4 + 1 : 0;  // dwords per staged row
+    // a signed-permutation map sends a T x T tile to a T x T tile: these bounds hold by construction
+    // (checked on the host); the guard only keeps a bad launch from writing outside LDS.
+    const bool fits = nrows <= ROWS && nd * 4 <= PITCH;
+    u32 lo[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) lo[c] = (n0[c] >= 0 && fits) ? (u32)((n0[c] - bx0) * PITCH + (n2[c] - bz0)) : 0xffffffffu;
+    // staging assignment: dword i of the tile -> (row, dword-in-row)
+    int sr[MAXLD], sc[MAXLD];
+#pragma unroll
+    for (int j = 0; j < MAXLD; ++j) {
+        const int i = tid + 256 * j;
+        if (fits && nd > 0 && i < nrows * nd) { sr[j] = i / nd; sc[j] = i - sr[j] * nd; }
+        else sr[j] = -1;
+    }
+    for (i64 y = y_beg; y < y_end; ++y) {
+#pragma unroll
+        for (int j = 0; j < MAXLD; ++j) {
+            if (sr[j] < 0) continue;
+            const i64 xs = bx0 + sr[j];
+            u32 v = 0;
+            if (!mask_src || mask_src[xs * H + y]) v = *(const u32*)(in + (xs * H + y) * D + bz0 + 4 * sc[j]);
+            *(u32*)(tile + sr[j] * PITCH + 4 * sc[j]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const i64 x = x0 + xl0 + 16 * k;
+            if (x >= W || z0 + zl >= D) continue;
+            u32 r = 0;
+            if (!mask_dst || mask_dst[x * H + y]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 o = lo[4 * k + q];
+                    if (o != 0xffffffffu) r |= (u32)tile[o] << (8 * q);
+                }
+            }
+            *(u32*)(out + (x * H + y) * D + z0 + zl) = r;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Validity table of a permutation-like step: bit z of row x is SciPy's bounds test on the f64
+// coordinates of output voxel (x, z).  Computed once per step (W*D cells) so that the sweeping
+// kernels below are pure integer work.  Row stride `nw` words; bits for z >= D are zero.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rot_valid(RotParams p, i64 W, i64 D, int nw, u32* __restrict__ bits) {
+    const i64 x = blockIdx.y;
+    const i64 z = (i64)blockIdx.x * 256 + threadIdx.x;
+    int a, b;
+    const bool v = x < W && z < D && source_of(p, x, z, W, D, &a, &b);
+    const u64 bal = __ballot(v);
+    const int lane = threadIdx.x & 63;
+    if ((z >> 5) < nw) {
+        if (lane == 0) bits[x * nw + (z >> 5)] = (u32)bal;
+        if (lane == 32) bits[x * nw + (z >> 5)] = (u32)(bal >> 32);
+    }
+}
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// K4: global_carve(binary, rgb, 90) fused: occ[x,y,z] = bm[x,y] && valid(x,z) && bm[c0 - z, y],
+// out = occ ? rgb[y,x,:] : 0 -- write-only, 3 B/voxel.  One wavefront per x-row; lane l owns the
+// 16-byte pieces p = l + 64k of the 3*D-byte column, so every wave store is 1 KiB contiguous.  A
+// piece starts at voxel 16p/3 with channel phase p % 3 and touches 6 voxels; their keep bits come
+// from the image rows bin_hw[y, :] staged in LDS, and the RGBRGB.. / keep byte patterns are cut out
+// of 20-byte sequences with v_alignbyte at the lane's phase.
+// ------------------------------------------------------------------------------------------------
+template <int TYC>
+__global__ __launch_bounds__(256) void k_global_carve90v(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3,
+                                                         u8* __restrict__ out_slab, const u32* __restrict__ vbits, int nw, int c0,
+                                                         i64 W, i64 H, i64 D, i64 x_first, i64 x_last) {
+    extern __shared__ u8 rows[];  // TYC image rows of W bytes
+    const int lane = threadIdx.x & 63;
+    const i64 x = x_first + (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 y_beg = (i64)blockIdx.y * TYC;
+    const i64 y_end = y_beg + TYC < H ? y_beg + TYC : H;
+    for (i64 i = threadIdx.x; i < (y_end - y_beg) * W; i += 256) rows[i] = bin_hw[y_beg * W + i] ? 1 : 0;
+    __syncthreads();
+    if (x >= x_last) return;
+    const i64 npieces = 3 * D / 16;
+    for (i64 pc = lane; pc < npieces; pc += 64) {
+        const int v0 = (int)((16 * pc) / 3);
+        const u32 ph = (u32)(pc % 3);
+        const u32* vr = vbits + x * nw + (v0 >> 5);
+        const u64 win = (u64)vr[0] | ((u64)vr[1] << 32);
+        const u32 vb6 = (u32)(win >> (v0 & 31)) & 0x3fu;
+        for (i64 y = y_beg; y < y_end; ++y) {
+            const u8* row = rows + (y - y_beg) * W;
+            u32 kb = 0;
+            if (row[x]) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+                    if ((vb6 >> e) & 1) kb |= (u32)(row[c0 - (v0 + e)] != 0) << e;
+            }
+            u32x4 r = (u32x4)(0u);
+            if (kb) {
+                const u8* px = rgb_hw3 + (y * W + x) * 3;
+                const u32 R = px[0], G = px[1], B = px[2];
+                const u32 S0 = R | (G << 8) | (B << 16) | (R << 24), S1 = G | (B << 8) | (R << 16) | (G << 24),
+                          S2 = B | (R << 8) | (G << 16) | (B << 24);
+                u32 m[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb >> e) & 1u);
+                const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
+                          w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
+                          w4 = m[5] & 0x0000ffffu;
+                r.x = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w1, w0, ph);
+                r.y = __builtin_amdgcn_alignbyte(S2, S1, ph) & __builtin_amdgcn_alignbyte(w2, w1, ph);
+                r.z = __builtin_amdgcn_alignbyte(S0, S2, ph) & __builtin_amdgcn_alignbyte(w3, w2, ph);
+                r.w = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w4, w3, ph);
+            }
+            __builtin_nontemporal_store(r, (u32x4*)(out_slab + ((x - x_first) * H + y) * D * 3) + pc);
+        }
+    }
+}
+
+// byte-store variant for widths that are not multiples of 16 (columns not 16-byte aligned)
+template <int TYC>
+__global__ __launch_bounds__(256) void k_global_carve90b(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3,
+                                                         u8* __restrict__ out_slab, const u32* __restrict__ vbits, int nw, int c0,
+                                                         i64 W, i64 H, i64 D, i64 x_first, i64 x_last) {
+    extern __shared__ u8 rows[];
+    const int lane = threadIdx.x & 63;
+    const i64 x = x_first + (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const i64 y_beg = (i64)blockIdx.y * TYC;
+    const i64 y_end = y_beg + TYC < H ? y_beg + TYC : H;
+    for (i64 i = threadIdx.x; i < (y_end - y_beg) * W; i += 256) rows[i] = bin_hw[y_beg * W + i] ? 1 : 0;
+    __syncthreads();
+    if (x >= x_last) return;
+    for (i64 z = lane; z < D; z += 64) {
+        const bool valid = (vbits[x * nw + (z >> 5)] >> (z & 31)) & 1u;
+        for (i64 y = y_beg; y < y_end; ++y) {
+            const u8* row = rows + (y - y_beg) * W;
+            const bool on = valid && row[x] && row[c0 - z];
+            const u8* px = rgb_hw3 + (y * W + x) * 3;
+            u8* o = out_slab + (((x - x_first) * H + y) * D + z) * 3;
+            o[0] = on ? px[0] : (u8)0; o[1] = on ? px[1] : (u8)0; o[2] = on ? px[2] : (u8)0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2' fast form for the 90-degree map n0 = c0 - z, n2 = x + c2 (c2 % 16 == 0, D % 16 == 0):
+// 128 x 128 byte tiles, 16-byte global loads and stores (full 128-byte lines on both sides), the
+// transpose done in registers: the source tile sits row-major in LDS (16-byte blocks XOR-swizzled by
+// the row group so that the column reads are bank-conflict free), each thread reads a 16-row x
+// 4-byte block with ds_read_b32 and transposes it with v_perm_b32 into four 16-byte output runs.
+// Global loads of plane y+1 are issued before plane y is computed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+__global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
+                                               const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
+                                               i64 W, i64 H, i64 D, int TY) {
+    __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
+    const int tid = threadIdx.x;
+    const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;
+    const i64 y_beg = (i64)blockIdx.z * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    // staging role: local source row lr = (tid >> 3) + 32 j, 16-byte block cb = tid & 7
+    const int cb = tid & 7;
+    const i64 rbase = (i64)c0 - (z0 + 127);             // source row of local row 0
+    const i64 scol = x0 + c2 + 16 * cb;                 // source column of this thread's block
+    const bool col_ok = scol >= 0 && scol + 15 < D;
+    // output role: z-run zg = tid & 7 (16 z), x-group xg = tid >> 3 (4 x)
+    const int zg = tid & 7, xg = tid >> 3;
+    const int g = 7 - zg;                               // row group holding this thread's 16 source rows
+    const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
+    const i64 zo = z0 + 16 * zg;
+    u32 vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 x = x0 + 4 * xg + i;
+        vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
+    }
+    u32x4 stg[4];
+    auto load_plane = [&](i64 y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 n0 = rbase + (tid >> 3) + 32 * j;
+            stg[j] = (u32x4)(0u);
+            if (col_ok && n0 >= 0 && n0 < W && (!mask_src || mask_src[n0 * H + y]))
+                stg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
+        }
+    };
+    load_plane(y_beg);
+    for (i64 y = y_beg; y < y_end; ++y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 3) + 32 * j;
+            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = stg[j];
+        }
+        __syncthreads();
+        if (y + 1 < y_end) load_plane(y + 1);
+        u32 d[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
+        u32 o[4][4];  // o[i][w]: output x = 4 xg + i, bytes q = 4w .. 4w+3 ; byte q <- d[15 - q].byte[i]
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 A = d[15 - 4 * w], B = d[14 - 4 * w], Cc = d[13 - 4 * w], E = d[12 - 4 * w];
+            const u32 t0 = perm(B, A, 0x05010400u), t1 = perm(B, A, 0x07030602u);
+            const u32 u0 = perm(E, Cc, 0x05010400u), u1 = perm(E, Cc, 0x07030602u);
+            o[0][w] = perm(u0, t0, 0x05040100u);
+            o[1][w] = perm(u0, t0, 0x07060302u);
+            o[2][w] = perm(u1, t1, 0x05040100u);
+            o[3][w] = perm(u1, t1, 0x07060302u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            if (x >= W || zo >= D) continue;
+            u32x4 r = (u32x4)(0u);
+            if (vb[i] && (!mask_dst || mask_dst[x * H + y])) {
+                r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
+                if (vb[i] != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
+                    u32 mw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 b4 = (vb[i] >> (4 * w)) & 0xfu;
+                        mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) |
+                                ((b4 & 8u) ? 0xff000000u : 0u);
+                    }
+                    r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
+                }
+            }
+            __builtin_nontemporal_store(r, (u32x4*)(out + (x * H + y) * D + zo));
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// true when the (x,z) part of (M, off) is a signed permutation up to 2^-40 with an offset within
+// 2^-20 of an integer: every coordinate of every voxel (< 2^20 per axis) is then within 2^-18 of an
+// integer and the step is an exact byte permutation (see the header of this file).
+bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D) {
+    if (W >= (1ll << 20) || D >= (1ll << 20)) return false;
+    const int idx[4] = {0, 2, 6, 8};
+    int r[4];
+    for (int k = 0; k < 4; ++k) {
+        const double v = M[idx[k]], n = nearbyint(v);
+        if (fabs(v - n) > 0x1p-40 || fabs(n) > 1.0) return false;
+        r[k] = (int)n;
+    }
+    if (abs(r[0]) + abs(r[1]) != 1 || abs(r[2]) + abs(r[3]) != 1 || abs(r[0]) + abs(r[2]) != 1) return false;
+    for (int h = 0; h < 3; h += 2)
+        if (fabs(off[h] - nearbyint(off[h])) > 0x1p-20) return false;
+    return true;
+}
+
+// integer form of a permutation-like step: n0 = r00*x + r02*z + c0, n2 = r20*x + r22*z + c2
+struct PermMap {
+    int r00, r02, r20, r22, c0, c2;
+};
+
+static PermMap perm_map(const double M[9], const double off[3]) {
+    PermMap m;
+    m.r00 = (int)nearbyint(M[0]); m.r02 = (int)nearbyint(M[2]); m.r20 = (int)nearbyint(M[6]); m.r22 = (int)nearbyint(M[8]);
+    m.c0 = (int)nearbyint(off[0]); m.c2 = (int)nearbyint(off[2]);
+    return m;
+}
+
+static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u32** bits, int* nw) {
+    const int n = (int)(((D + 63) / 64) * 2 + 2);
+    void* buf;
+    PB3D_TRY(pb3d_scratch(ctx, 10, (size_t)W * n * sizeof(u32), &buf));
+    PB3D_HIP(hipMemsetAsync(buf, 0, (size_t)W * n * sizeof(u32), ctx->stream));
+    dim3 grid((unsigned)((D + 255) / 256), (unsigned)W);
+    hipLaunchKernelGGL(k_rot_valid, grid, dim3(256), 0, ctx->stream, p, W, D, n, (u32*)buf);
+    PB3D_CHECK_LAUNCH();
+    *bits = (u32*)buf; *nw = n;
+    return PB3D_OK;
+}
+
+int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
+                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out) {
+    PB3D_REQUIRE(D % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 3u) == 0, "pb3d_rotate_perm: needs D %% 4 == 0");
+    RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    const PermMap pm = perm_map(M, off);
+    const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
+    if (rot90 && D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0 && W <= 65535 && H <= 65535) {
+        u32* bits; int nw;
+        PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
+        int TY = 32;
+        const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
+        while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
+        dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
+        hipLaunchKernelGGL(k_rot90, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
+                           pm.c0, pm.c2, W, H, D, TY);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
+    int TY = 32;
+    const i64 tiles = ((D + T - 1) / T) * ((W + T - 1) / T);
+    while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 8) TY >>= 1;
+    dim3 grid((unsigned)((D + T - 1) / T), (unsigned)((W + T - 1) / T), (unsigned)((H + TY - 1) / TY));
+    PB3D_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, "pb3d_rotate_perm: grid too large");
+    hipLaunchKernelGGL(k_rotate_perm, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, p, W, H, D, TY);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+// fused global_carve for angle_interval == 90.  Output slab x in [x0, x1).
+int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, i64 h, i64 w, const double M[9],
+                               const double off[3], i64 x0, i64 x1, u8* d_out_slab) {
+    const i64 W = w, H = h, D = w;
+    RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    const PermMap pm = perm_map(M, off);
+    PB3D_REQUIRE(pm.r00 == 0 && pm.r02 == -1, "pb3d_global_carve: unexpected 90-degree map");
+    constexpr int TYC = 16;
+    const size_t lds = (size_t)TYC * (size_t)W;
+    PB3D_REQUIRE(lds <= 64 * 1024, "pb3d_global_carve: mask too wide for the fused path");
+    u32* bits; int nw;
+    PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
+    dim3 grid((unsigned)((x1 - x0 + 3) / 4), (unsigned)((H + TYC - 1) / TYC));
+    PB3D_REQUIRE(grid.y <= 65535u, "pb3d_global_carve: grid too large");
+    const bool vec = (D % 16 == 0) && (((uintptr_t)d_out_slab & 15u) == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_global_carve90v<TYC>, grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
+                           (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
+    else
+        hipLaunchKernelGGL(k_global_carve90b<TYC>, grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
+                           (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}

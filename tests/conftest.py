@@ -28,6 +28,9 @@ def golden():
 def oracle():
     from oracle import oracle as orc
     orc.lib()
+    # stay inside the CPU share of the box (16 per GPU on the GPU box; 8 here): OpenMP's default is every
+    # hardware thread it can see, which oversubscribes badly on small inputs
+    orc.set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     return orc
 
 

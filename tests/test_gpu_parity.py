@@ -184,7 +184,7 @@ def test_process_vs_oracle_angles(pb3d_gpu, oracle):
         for kind in ("bin", "full"):
             g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "bin" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
             m = rng.random((H, W)) < 0.9
-            for ai in (90, 45, 30, 10, 7, 1 if W < 40 else 15, 91, 200):
+            for ai in (90, 45, 30, 10 if W < 100 else 18, 7 if W < 40 else 23, 1 if W < 10 else 15, 91, 200):
                 got = pb3d_gpu.process_voxel_grid(g, m, ai)
                 want = oracle.process_voxel_grid(g, m, ai)
                 assert np.array_equal(got, want), (W, H, D, kind, ai, int((got != want).sum()))
@@ -281,3 +281,43 @@ def test_full_size_carve_properties(pb3d_gpu):
         assert int(b.astype(np.uint64).sum()) == int(a[m_wh[x0:x0 + planes].astype(bool)].astype(np.uint64).sum())
     for buf in (d_in, d_out, d_out2, d_mwh):
         buf.free()
+
+
+def test_process90_tiled_permutation_sizes(pb3d_gpu, oracle):
+    """the LDS-tiled 90-degree path (W + D even, D % 4 == 0) on sizes that are not tile multiples, next to
+    shapes that must fall back to the generic kernel (W + D odd -> half-integer coordinates; D % 4 != 0)."""
+    rng = np.random.default_rng(29)
+    for (W, H, D) in [(100, 7, 100), (68, 5, 132), (132, 3, 68), (64, 2, 64), (4, 3, 4), (260, 4, 260), (200, 2, 72),
+                      (130, 3, 62), (63, 4, 64), (65, 2, 65), (128, 3, 128), (256, 2, 256), (192, 5, 192)]:
+        for kind in ("bin", "full"):
+            g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "bin" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+            m = rng.random((H, W)) < 0.85
+            got = pb3d_gpu.process_voxel_grid(g, m, 90)
+            want = oracle.process_voxel_grid(g, m, 90)
+            assert np.array_equal(got, want), (W, H, D, kind, int((got != want).sum()))
+
+
+def test_global_carve_slabs_device(pb3d_gpu, oracle):
+    """fused global_carve: X-slabs computed independently (the sharded form) concatenate to the full result."""
+    import synth_host
+    from pb3d import device as dev
+    for S in (64, 96, 80, 128):
+        lab, binary, rgb = synth_host.mask16(S)
+        want = oracle.global_carve(binary, rgb, 90)
+        d_b = dev.from_numpy(binary); d_rgb = dev.from_numpy(rgb)
+        full = dev.DeviceBuffer(S * S * S * 3)
+        dev.global_carve(d_b, d_rgb, S, S, 90, full)
+        assert np.array_equal(full.download((S, S, S, 3)), want), S
+        for nr in (2, 4):
+            parts = []
+            for r in range(nr):
+                x0, x1 = pb3d_gpu.dist.slab_bounds(S, r, nr)
+                slab = dev.DeviceBuffer((x1 - x0) * S * S * 3)
+                dev.global_carve(d_b, d_rgb, S, S, 90, slab, x0, x1)
+                parts.append(slab.download((x1 - x0, S, S, 3)))
+            assert np.array_equal(np.concatenate(parts, 0), want), (S, nr)
+    # widths that are not multiples of 16 go through the byte-store variant; non-square images too
+    for (h, w) in [(50, 50), (33, 70), (64, 40), (20, 144)]:
+        lab, binary, rgb = synth_host.mask16(max(h, w))
+        binary, rgb = np.ascontiguousarray(binary[:h, :w]), np.ascontiguousarray(rgb[:h, :w])
+        assert np.array_equal(pb3d_gpu.global_carve(binary, rgb, 90), oracle.global_carve(binary, rgb, 90)), (h, w)
