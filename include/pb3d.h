@@ -162,6 +162,25 @@ int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b,
 int pb3d_partwise_iou(pb3d_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t npix,
                       const uint8_t* colors, int ncolors, int64_t* inter, int64_t* uni);
 
+/* ---- part-wise deformation, reference utils/deformation_estimation.py:70-98 (deform_coords) -------
+ * Seven jitters (0, +-0.25 per axis) of the part's points (voxel indices as float32), each centred on
+ * its own mean, x/z scaled by sxz and pushed by kx/kz * sign, y scaled by sy and shifted by -ky (the
+ * caller forms kx = shift_xz*W/W_img, ky = shift_y*H/H_img, kz = shift_xz*D/W_img as Python floats, :76-78),
+ * rounded half-to-even; the result is np.unique(axis=0): unique rows in lexicographic (x,y,z) order as
+ * int64.  count, then fill with a buffer of n_unique rows.  paint writes rgb at grid[z,y,x] of every
+ * in-bounds deformed coordinate (:120-124, :306-309 for a uniformly coloured part); scatter_colors is the
+ * general grid[z,y,x] = cols[k] assignment for unique rows. */
+int pb3d_deform_count_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, double sxz, double sy, double kx, double ky, double kz,
+                          int64_t* n_unique);
+int pb3d_deform_fill_dev(pb3d_ctx* ctx, int64_t n_unique, int64_t* d_coords);
+int pb3d_deform_count(pb3d_ctx* ctx, const float* pts, int64_t n, double sxz, double sy, double kx, double ky, double kz,
+                      int64_t* n_unique);
+int pb3d_deform_fill(pb3d_ctx* ctx, int64_t n_unique, int64_t* coords);
+int pb3d_deform_paint_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, double sxz, double sy, double kx, double ky, double kz,
+                          int64_t A0, int64_t A1, int64_t A2, const uint8_t rgb[3], uint8_t* d_grid);
+int pb3d_scatter_colors_dev(pb3d_ctx* ctx, const int64_t* d_coords, const uint8_t* d_cols, int64_t m, int64_t A0, int64_t A1,
+                            int64_t A2, uint8_t* d_grid);
+
 /* ---- seeded synthetic inputs generated on the device ---------------------
  * mask16: labels (S,S) uint8 in 0..15 by the closed formula scaled from S=1024; binary and
  * rgb derive from it.  Any output pointer may be NULL.  sem grid: palette[label16 of a

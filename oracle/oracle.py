@@ -305,3 +305,56 @@ def compute_partwise_iou(proj_mask, gt_mask, part_colors):
     for n, i, u in zip(names, inter, uni):
         per[n] = (i / u) if u > 0 else 0.0
     return per, np.mean(list(per.values()))
+
+
+# ---- A18: notebook-3 deformation closures (reference utils/deformation_estimation.py) -----------------
+def deform_coords(coords, image_shape, voxel_shape, deform):
+    """:70-98 -- unique, lexicographically sorted int64 rows of the 7-jitter deformation."""
+    p = np.ascontiguousarray(coords, np.float32)
+    H_img, W_img = image_shape
+    D, H, W = voxel_shape
+    kx = deform["shift_xz"] * (W / float(W_img))
+    ky = deform["shift_y"] * (H / float(H_img))
+    kz = deform["shift_xz"] * (D / float(W_img))
+    out = np.empty((7 * len(p), 3), np.int64)
+    lib().orc_deform_coords.restype = _i64
+    m = lib().orc_deform_coords(p.ctypes.data_as(C.POINTER(C.c_float)), _i64(len(p)), C.c_double(deform["scale_xz"]),
+                                C.c_double(deform["scale_y"]), C.c_double(kx), C.c_double(ky), C.c_double(kz),
+                                out.ctypes.data_as(C.POINTER(_i64)))
+    return out[:m].copy()
+
+
+def deform_part(voxel_grid, part_labels, part, deform, image_shape):
+    """:102-118 / :265-275: in-bounds deformed coordinates of one part and the colours paired with them."""
+    voxel_shape = voxel_grid.shape[:3]
+    coords, colors = get_voxel_points_by_parts(voxel_grid, part_labels, [part])
+    if len(coords) == 0:
+        return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.uint8)
+    cd = deform_coords(coords, image_shape, voxel_shape, deform)
+    valid = ((cd[:, 0] >= 0) & (cd[:, 0] < voxel_shape[2]) & (cd[:, 1] >= 0) & (cd[:, 1] < voxel_shape[1]) &
+             (cd[:, 2] >= 0) & (cd[:, 2] < voxel_shape[0]))
+    cd = cd[valid]
+    reps = max(1, int(len(cd) / len(colors)) + 1)
+    return cd, np.repeat(colors, repeats=reps, axis=0)[:len(cd)]
+
+
+def evaluate_part_deform(voxel_grid, part_labels, part, deform, image, cam_params):
+    """save_params, :262-284: projection of the deformed part and its IoU against the image."""
+    cd, cols = deform_part(voxel_grid, part_labels, part, deform, image.shape[:2])
+    proj = project_colored_voxels(cd.astype(np.float32), cols, cam_params["cam_pos"], cam_params["target"],
+                                  cam_params["f"], cam_params["cx"], cam_params["cy"], image.shape[0], image.shape[1])
+    per, _ = compute_partwise_iou(proj, image, {part: part_labels[part]})
+    return proj, float(per[part])
+
+
+def build_deformed_grid(voxel_grid, part_labels, saved_params, image_shape):
+    """save_deformed_grid, :288-313: every saved part painted into a zero grid, in part_labels order."""
+    out = np.zeros_like(voxel_grid, dtype=np.uint8)
+    for part in part_labels:
+        if part not in saved_params:
+            continue
+        cd, cols = deform_part(voxel_grid, part_labels, part, saved_params[part]["deform"], image_shape)
+        if cd.size == 0:
+            continue
+        out[cd[:, 2], cd[:, 1], cd[:, 0]] = cols
+    return out

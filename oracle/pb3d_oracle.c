@@ -398,3 +398,46 @@ void orc_partwise_iou(const u8* a, const u8* b, i64 npix, const u8* colors, int 
         inter[k] = in; uni[k] = un;
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * A18: deform_coords -- reference utils/deformation_estimation.py:70-98 (closure of the
+ * notebook-3 viewer).  Seven jitters (0, +-0.25 per axis) of the float32 points, each
+ * centred on its own mean, scaled / shifted per axis in float64, rounded half-to-even to
+ * integers, then np.unique(axis=0): the lexicographically sorted set of (x,y,z) rows.
+ *   kx = shift_xz * pix2vox_x, ky = shift_y * pix2vox_y, kz = shift_xz * pix2vox_z are formed by the
+ *   caller as Python floats exactly as upstream (:76-81).
+ * Returns the number of unique rows; out (capacity 7n rows of int64[3]) receives them.
+ * ---------------------------------------------------------------------------------- */
+static int orc_cmp3(const void* a, const void* b) {
+    const i64* p = (const i64*)a; const i64* q = (const i64*)b;
+    for (int k = 0; k < 3; ++k) { if (p[k] < q[k]) return -1; if (p[k] > q[k]) return 1; }
+    return 0;
+}
+
+static inline double orc_sign(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : v); }
+
+i64 orc_deform_coords(const float* pts, i64 n, double sxz, double sy, double kx, double ky, double kz, i64* out) {
+    static const double offs[7][3] = {{0, 0, 0}, {0.25, 0, 0}, {-0.25, 0, 0}, {0, 0.25, 0}, {0, -0.25, 0}, {0, 0, 0.25}, {0, 0, -0.25}};
+    if (n == 0) return 0;
+    for (int j = 0; j < 7; ++j) {
+        double sum[3] = {0, 0, 0};
+        for (i64 i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) sum[a] += (double)pts[3 * i + a] + offs[j][a];   /* np.mean: rows added in order */
+        double ctr[3] = {sum[0] / (double)n, sum[1] / (double)n, sum[2] / (double)n};
+        for (i64 i = 0; i < n; ++i) {
+            double c0 = ((double)pts[3 * i + 0] + offs[j][0]) - ctr[0];
+            double c1 = ((double)pts[3 * i + 1] + offs[j][1]) - ctr[1];
+            double c2 = ((double)pts[3 * i + 2] + offs[j][2]) - ctr[2];
+            double d0 = c0 * sxz + kx * orc_sign(c0);
+            double d1 = c1 * sy - ky;
+            double d2 = c2 * sxz + kz * orc_sign(c2);
+            i64* o = out + 3 * (j * n + i);
+            o[0] = (i64)nearbyint(d0 + ctr[0]); o[1] = (i64)nearbyint(d1 + ctr[1]); o[2] = (i64)nearbyint(d2 + ctr[2]);
+        }
+    }
+    qsort(out, (size_t)(7 * n), 3 * sizeof(i64), orc_cmp3);
+    i64 m = 0;
+    for (i64 i = 0; i < 7 * n; ++i)
+        if (m == 0 || orc_cmp3(out + 3 * i, out + 3 * (m - 1)) != 0) { if (m != i) memcpy(out + 3 * m, out + 3 * i, 3 * sizeof(i64)); ++m; }
+    return m;
+}

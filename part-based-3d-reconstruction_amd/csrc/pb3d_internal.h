@@ -38,6 +38,12 @@ struct pb3d_ctx {
         u8 colors[3 * 32];
         bool valid;
     } pts;
+    // state kept between pb3d_deform_count and pb3d_deform_fill
+    struct {
+        int ox, oy, oz;
+        i64 X, Y, Z, n;
+        bool valid;
+    } deform;
     // RCCL (loaded lazily with dlopen; see comm.hip)
     void* rccl_lib;
     void* rccl_comm;

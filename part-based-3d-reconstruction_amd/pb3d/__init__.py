@@ -8,6 +8,7 @@ reference `utils` package so notebooks 1-3 run unchanged.
 from . import _lib, device, dist  # noqa: F401
 from .camera_estimation import compute_partwise_iou  # noqa: F401
 from .camera_geometry import look_at_rotation, project  # noqa: F401
+from .deformation_estimation import build_deformed_grid, deform_coords, deform_part, evaluate_part_deform  # noqa: F401
 from .config import INTERIOR_PARTS, MAX_DIM, PART_COLORS, PART_COLORS_NP  # noqa: F401
 from .projection_utils import project_colored_voxels  # noqa: F401
 from .voxel_carving_utils import (apply_colored_mask_to_voxel_grid, carve_voxel_grid_with_masks, global_carve,  # noqa: F401

@@ -62,6 +62,12 @@ _SIGNATURES = {
     "pb3d_project": [vp, vp, C.c_int, u8p, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, u8p],
     "pb3d_partwise_iou_dev": [vp, vp, vp, i64, u8p, C.c_int, i64p, i64p],
     "pb3d_partwise_iou": [vp, u8p, u8p, i64, u8p, C.c_int, i64p, i64p],
+    "pb3d_deform_count_dev": [vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64p],
+    "pb3d_deform_fill_dev": [vp, i64, vp],
+    "pb3d_deform_count": [vp, C.POINTER(C.c_float), i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64p],
+    "pb3d_deform_fill": [vp, i64, i64p],
+    "pb3d_deform_paint_dev": [vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, i64, i64, u8p, vp],
+    "pb3d_scatter_colors_dev": [vp, vp, vp, i64, i64, i64, i64, vp],
     "pb3d_synth_mask16_dev": [vp, i64, vp, vp, vp, vp],
     "pb3d_synth_sem_dev": [vp, i64, i64, i64, i64, C.c_uint64, vp],
     "pb3d_synth_occ_dev": [vp, i64, i64, i64, i64, C.c_uint64, vp],

@@ -321,3 +321,36 @@ def test_global_carve_slabs_device(pb3d_gpu, oracle):
         lab, binary, rgb = synth_host.mask16(max(h, w))
         binary, rgb = np.ascontiguousarray(binary[:h, :w]), np.ascontiguousarray(rgb[:h, :w])
         assert np.array_equal(pb3d_gpu.global_carve(binary, rgb, 90), oracle.global_carve(binary, rgb, 90)), (h, w)
+
+
+def test_deformation_loop_f8(pb3d_gpu, oracle, golden):
+    """BASELINE config 5: the notebook-3 deformation loop (deform -> bounds -> paint -> project -> IoU) against
+    the headless drive of the reference's widget closures, and against the oracle on a random cloud."""
+    g = golden("f8_deformation")
+    meta = json.load(open(os.path.join(GOLDEN, "f8_deformation.json")))
+    grid = np.load(os.path.join(GOLDEN, "stored_Akbar_voxel_grid.npz"))["voxel_grid"]
+    PC = pb3d_gpu.PART_COLORS
+    r = meta["rand"]
+    got = pb3d_gpu.deform_coords(g["rand_pts"], r["image_shape"], r["voxel_shape"], r["deform"])
+    assert got.dtype == np.int64 and np.array_equal(got, g["rand_coords"])
+    cams = _cams("Akbar")["front"]
+    saved = {}
+    for part, c in meta["cases"].items():
+        coords, _ = pb3d_gpu.get_voxel_points_by_parts(grid, PC, [part])
+        cd = pb3d_gpu.deform_coords(coords, meta["image_shape"], meta["voxel_shape"], c["deform"])
+        assert len(cd) == c["n_deformed"] and sha(cd) == c["coords_sha256"], part
+        _, iou = pb3d_gpu.evaluate_part_deform(grid, PC, part, c["deform"], g["front_mask"], cams)
+        assert iou == c["iou"], (part, iou, c["iou"])
+        saved[part] = {"deform": c["deform"], "iou": iou}
+    full = pb3d_gpu.build_deformed_grid(grid, PC, saved, meta["image_shape"])
+    assert sha(full) == meta["deformed_grid_sha256"]
+    rng = np.random.default_rng(31)
+    for _ in range(4):
+        pts = rng.integers(-5, 70, (int(rng.integers(1, 3000)), 3)).astype(np.float32)
+        dv = dict(scale_y=float(rng.uniform(0.5, 2)), shift_y=float(rng.integers(-100, 100)), scale_xz=float(rng.uniform(0.5, 2)),
+                  shift_xz=float(rng.integers(-100, 100)))
+        a = pb3d_gpu.deform_coords(pts, (77, 131), (64, 70, 66), dv)
+        b = oracle.deform_coords(pts, (77, 131), (64, 70, 66), dv)
+        assert np.array_equal(a, b)
+    with pytest.raises(pb3d_gpu._lib.Pb3dError, match="voxel indices"):
+        pb3d_gpu.deform_coords(np.array([[0.5, 1, 2]], np.float32), (10, 10), (4, 4, 4), dict(scale_y=1.0, shift_y=0.0, scale_xz=1.0, shift_xz=0.0))

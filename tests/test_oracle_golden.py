@@ -183,3 +183,28 @@ def test_projection_synth_modes(oracle, golden):
         H, W = (int(v) for v in g[f"hw_{i}"])
         out = oracle.project_colored_voxels(g[f"pts_{i}"], g[f"cols_{i}"], g[f"cam_{i}"], g[f"tgt_{i}"], f, cx, cy, H, W)
         assert np.array_equal(out, g[f"out_{i}"]), i
+
+
+def test_deformation_closures_f8(oracle, golden):
+    """notebook-3 deformation loop (BASELINE config 5) against the headless widget drive of the reference."""
+    g = golden("f8_deformation")
+    meta = json.load(open(os.path.join(GOLDEN, "f8_deformation.json")))
+    grid = np.load(os.path.join(GOLDEN, "stored_Akbar_voxel_grid.npz"))["voxel_grid"]
+    PC = oracle.PART_COLORS
+    r = meta["rand"]
+    got = oracle.deform_coords(g["rand_pts"], r["image_shape"], r["voxel_shape"], r["deform"])
+    assert got.dtype == np.int64 and np.array_equal(got, g["rand_coords"])
+    cams = _cams("Akbar")["front"]
+    saved = {}
+    for part, c in meta["cases"].items():
+        coords, _ = oracle.get_voxel_points_by_parts(grid, PC, [part])
+        assert len(coords) == c["n_points"]
+        cd = oracle.deform_coords(coords, meta["image_shape"], meta["voxel_shape"], c["deform"])
+        assert len(cd) == c["n_deformed"] and sha(cd) == c["coords_sha256"], part
+        if f"coords_{part}" in g.files:
+            assert np.array_equal(cd, g[f"coords_{part}"])
+        _, iou = oracle.evaluate_part_deform(grid, PC, part, c["deform"], g["front_mask"], cams)
+        assert iou == c["iou"], (part, iou, c["iou"])
+        saved[part] = {"deform": c["deform"], "iou": iou}
+    full = oracle.build_deformed_grid(grid, PC, saved, meta["image_shape"])
+    assert sha(full) == meta["deformed_grid_sha256"] and np.array_equal(full, g["deformed_grid"])
