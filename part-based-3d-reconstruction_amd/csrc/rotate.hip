@@ -76,7 +76,8 @@ __device__ __forceinline__ u32 sample(const u8* __restrict__ in, const Cell& c, 
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ in, u8* __restrict__ out,
                                                         const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D,
-                                                        int TY) {
+                                                        int TY, const int* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;   // second pass of a table-driven step: only when a value > 1 was seen
     const int lane = threadIdx.x & 63;
     const i64 x = (i64)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 z0 = ((i64)blockIdx.x * 64 + lane) * 4;
@@ -107,6 +108,151 @@ __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generic-angle step for 0/1 data, LDS-tiled.  Output tile 64 x 64 (x,z) per workgroup, swept over
+// TY planes.
+//  * the f64 coordinates / weights of a cell depend on (x,z) only: they are evaluated ONCE per
+//    workgroup and folded into a 16-bit lookup table per cell: bit b of the table is SciPy's result
+//    for the tap pattern b = v00 | v01<<1 | v10<<2 | v11<<3 (partial sums formed in SciPy's tap order
+//    from the exact products w_x*w_z; 1.0*w == w and a zero tap adds +0.0, so this IS the reference
+//    arithmetic for 0/1 inputs);
+//  * per plane the rotated footprint (bounding box of the tile's sources incl. the second taps) is
+//    staged into LDS with coalesced dword row loads (next plane prefetched into registers); each
+//    output is then 4 LDS byte reads + one table lookup -- pure integer work in the plane loop;
+//  * if ANY staged byte is > 1 the workgroup raises *big_flag: the launcher then lets the arithmetic
+//    kernel k_rotate_generic redo the step (it starts only when the flag is set), so 0..255 grids
+//    stay exact without a host round trip.
+// ------------------------------------------------------------------------------------------------
+constexpr int LT = 64;              // tile edge
+constexpr int LPITCH = 104;         // LDS row pitch (bytes, dword multiple)
+constexpr int LROWS = 100;
+constexpr int LMAXLD = (LROWS * (LPITCH / 4) + 255) / 256;
+
+__device__ __forceinline__ u32 lut_of(const Cell& c) {
+    const double p00 = __dmul_rn(c.wx0, c.wz0), p01 = __dmul_rn(c.wx0, c.wz1), p10 = __dmul_rn(c.wx1, c.wz0),
+                 p11 = __dmul_rn(c.wx1, c.wz1);
+    u32 lut = 0;
+#pragma unroll
+    for (int b = 1; b < 16; ++b) {
+        double acc = 0.0;
+        if (b & 1) acc = __dadd_rn(acc, p00);
+        if (b & 2) acc = __dadd_rn(acc, p01);
+        if (b & 4) acc = __dadd_rn(acc, p10);
+        if (b & 8) acc = __dadd_rn(acc, p11);
+        // uint8 store rule: acc > 0 ? trunc(acc + 0.5) : 0 ; the weights sum to ~1 so the value is 0 or 1
+        if (acc > 0.0 && __dadd_rn(acc, 0.5) >= 1.0) lut |= 1u << b;
+    }
+    return lut;
+}
+
+#ifndef LUT_WAVES
+#define LUT_WAVES 4
+#endif
+__global__ __launch_bounds__(256, LUT_WAVES) void k_rotate_lut(const u8* __restrict__ in, u8* __restrict__ out,
+                                                       const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D, int TY,
+                                                       int* __restrict__ big_flag) {
+    __shared__ __attribute__((aligned(16))) u8 tile[LROWS * LPITCH];
+    __shared__ int bb[4];
+    const int tid = threadIdx.x;
+    const i64 x0 = (i64)blockIdx.y * LT, z0 = (i64)blockIdx.x * LT;
+    const i64 y_beg = (i64)blockIdx.z * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+    __syncthreads();
+    const int zl = (tid & 15) * 4, xl0 = tid >> 4;   // 16 cells: rows xl0 + 16k, z = zl + q
+    u32 src[16];   // s0 << 16 | s2   (0xffffffff: outside)
+    u32 lut[16];
+    int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const i64 x = x0 + xl0 + 16 * (c >> 2), z = z0 + zl + (c & 3);
+        src[c] = 0xffffffffu; lut[c] = 0;
+        if (x < W && z < D) {
+            const Cell cell = make_cell(p, x, z, W, D);
+            if (cell.s0 >= 0) {
+                src[c] = ((u32)cell.s0 << 16) | (u32)cell.s2;
+                lut[c] = lut_of(cell);
+                // second taps are touched only when their weight is non-zero: keep those inside the box
+                const int e0 = cell.s0 + (cell.wx1 != 0.0 ? 1 : 0), e2 = cell.s2 + (cell.wz1 != 0.0 ? 1 : 0);
+                mn0 = cell.s0 < mn0 ? cell.s0 : mn0; mx0 = e0 > mx0 ? e0 : mx0;
+                mn2 = cell.s2 < mn2 ? cell.s2 : mn2; mx2 = e2 > mx2 ? e2 : mx2;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one cell at a time: keeps the f64 temporaries from piling up
+    }
+    if (mx0 >= 0) { atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); atomicMin(&bb[2], mn2); atomicMax(&bb[3], mx2); }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1], bz0 = bb[2] & ~3, bz1 = bb[3];
+    const bool any_valid = bx1 >= 0;
+    const int nrows = any_valid ? bx1 - bx0 + 1 : 0;
+    const int nd = any_valid ? (bz1 - bz0) / 4 + 1 : 0;
+    // +1 row / +1 byte so that zero-weight second taps still read inside the LDS box
+    const bool fits = nrows + 1 <= LROWS && nd * 4 + 4 <= LPITCH;
+    if (any_valid && !fits) { if (tid == 0) atomicOr(big_flag, 1); }   // cannot happen for rotations; fall back exactly
+    u32 cellw[16];   // lut << 16 | LDS offset (0xffff: outside)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        u32 o = 0xffffu;
+        if (src[c] != 0xffffffffu && fits) o = (u32)(((int)(src[c] >> 16) - bx0) * LPITCH + ((int)(src[c] & 0xffffu) - bz0));
+        cellw[c] = (lut[c] << 16) | o;
+    }
+    const int ndw = (any_valid && fits) ? nrows * nd : 0;
+    const u32 ndmagic = nd > 1 ? (u32)(((1ull << 32) + nd - 1) / nd) : 0;   // i / nd, exact while i * nd < 2^32
+    const bool al = (D & 3) == 0 && (((uintptr_t)in) & 3u) == 0;           // rows start dword-aligned
+    u32 stg[LMAXLD];
+    auto load_plane = [&](i64 y) {
+#pragma unroll
+        for (int j = 0; j < LMAXLD; ++j) {
+            const int i = tid + 256 * j;
+            stg[j] = 0;
+            if (i < ndw) {
+                const int r = nd > 1 ? (int)__umulhi((u32)i, ndmagic) : i;
+                const i64 col = (i64)bz0 + 4 * (i - r * nd);
+                const u8* sp = in + (((i64)bx0 + r) * H + y) * D + col;
+                if (al && col + 3 < D) stg[j] = *(const u32*)sp;
+                else { for (int b = 0; b < 4; ++b) if (col + b < D) stg[j] |= (u32)sp[b] << (8 * b); }
+            }
+        }
+    };
+    load_plane(y_beg);
+    u32 hib = 0;
+    for (i64 y = y_beg; y < y_end; ++y) {
+#pragma unroll
+        for (int j = 0; j < LMAXLD; ++j) {
+            const int i = tid + 256 * j;
+            if (i < ndw) {
+                const int r = nd > 1 ? (int)__umulhi((u32)i, ndmagic) : i;
+                *(u32*)(tile + r * LPITCH + 4 * (i - r * nd)) = stg[j];
+                hib |= stg[j];
+            }
+        }
+        __syncthreads();
+        if (y + 1 < y_end) load_plane(y + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const i64 x = x0 + xl0 + 16 * k;
+            if (x >= W || z0 + zl >= D) continue;
+            u32 r = 0;
+            if (!mask_wh || mask_wh[x * H + y]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 cw = cellw[4 * k + q], o = cw & 0xffffu;
+                    if (o == 0xffffu) continue;
+                    // "& 1": a zero-weight second tap may sit on an unstaged (stale) byte; its table bit is a don't-care
+                    const u32 bits = ((u32)tile[o] & 1u) | (((u32)tile[o + 1] & 1u) << 1) | (((u32)tile[o + LPITCH] & 1u) << 2) |
+                                     (((u32)tile[o + LPITCH + 1] & 1u) << 3);
+                    r |= ((cw >> (16 + bits)) & 1u) << (8 * q);
+                }
+            }
+            u8* op = out + (x * H + y) * D + z0 + zl;
+            if (z0 + zl + 3 < D && (((uintptr_t)op) & 3u) == 0) *(u32*)op = r;
+            else { for (int q = 0; q < 4; ++q) if (z0 + zl + q < D) op[q] = (u8)(r >> (8 * q)); }
+        }
+        __syncthreads();
+    }
+    if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
+}
+
 bool is_zero(double v) { return v == 0.0; }
 
 }  // namespace
@@ -118,6 +264,26 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     PB3D_REQUIRE(W < (1ll << 30) && D < (1ll << 30), "pb3d_rotate_carve: axis too long");
     if (W * H * D == 0) return PB3D_OK;
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    // Large grids: table-driven tiled kernel first; the arithmetic kernel follows and runs only if the
+    // first one met a value > 1 (device-side flag, no host round trip).  Small grids (launch-bound):
+    // the arithmetic kernel alone.  The footprint of a 64 x 64 tile must fit the LDS box: true for
+    // rotations (row sums of |M| <= sqrt 2).
+    const double ext0 = fabs(M[0]) + fabs(M[2]), ext2 = fabs(M[6]) + fabs(M[8]);
+    const bool tiled = ext0 <= 1.45 && ext2 <= 1.45 && W < 65536 && D < 65536 && W * H * D >= (1ll << 21);
+    int* flag = nullptr;
+    if (tiled) {
+        void* f;
+        PB3D_TRY(pb3d_scratch(ctx, 15, 64, &f));
+        flag = (int*)f;
+        PB3D_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+        int TYL = 32;
+        const i64 tiles = ((D + LT - 1) / LT) * ((W + LT - 1) / LT);
+        while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
+        dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
+        PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
+        hipLaunchKernelGGL(k_rotate_lut, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
+        PB3D_CHECK_LAUNCH();
+    }
     int TY = 16;
     // keep at least ~8 blocks per CU in flight for small grids
     const i64 tiles_xz = ((D + 255) / 256) * ((W + 3) / 4);
@@ -126,9 +292,9 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     PB3D_REQUIRE(grid.y <= 65535u * 1024u && grid.z <= 65535u, "pb3d_rotate_carve: grid too large");
     const bool pack = (D % 4 == 0) && (((uintptr_t)d_out & 3u) == 0);
     if (pack)
-        hipLaunchKernelGGL(k_rotate_generic<true>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY);
+        hipLaunchKernelGGL(k_rotate_generic<true>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag);
     else
-        hipLaunchKernelGGL(k_rotate_generic<false>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY);
+        hipLaunchKernelGGL(k_rotate_generic<false>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
