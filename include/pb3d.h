@@ -181,6 +181,29 @@ int pb3d_deform_paint_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, double s
 int pb3d_scatter_colors_dev(pb3d_ctx* ctx, const int64_t* d_coords, const uint8_t* d_cols, int64_t m, int64_t A0, int64_t A1,
                             int64_t A2, uint8_t* d_grid);
 
+/* ---- connected components and the steps built on them (rows N1/N2) ---------------------------------
+ * pb3d_label_color_dev: scipy.ndimage.label(all(grid == color, axis=-1)) with the default 6-connected
+ * structure (call sites reference utils/voxel_carving_utils.py:175, :254): int32 labels 1..ncomp numbered in
+ * raster order of each component's first voxel, 0 elsewhere.  pb3d_component_stats_dev: per component the
+ * bounding box (lo inclusive, hi exclusive -- :184-185), voxel count and coordinate sums (for the means of
+ * :259), returned in host arrays.  crop_occupancy / component_paste are the per-component steps of
+ * left_right_guided_carve (:190-192, :197-201); recolor_components is :263-265; extrude is
+ * extrude_from_surface (:213-248): out = grid with `depth` cells from the first occupied voxel along the
+ * axis painted fill_color (NULL = zeros) where the 2-D mask allows (axis 2: valid[x*H+y]; axis 0:
+ * valid[y*valid_w + z], the upstream indexing of its (H,W) mask). */
+int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
+                         int32_t* d_labels, int64_t* ncomp);
+int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0, int64_t A1, int64_t A2, int64_t ncomp,
+                             int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum);
+int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
+                            const int64_t hi[3], uint8_t* d_occ);
+int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
+                             int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved);
+int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                                const uint8_t new_color[3], uint8_t* d_grid_rgb);
+int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
+                     int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out);
+
 /* ---- seeded synthetic inputs generated on the device ---------------------
  * mask16: labels (S,S) uint8 in 0..15 by the closed formula scaled from S=1024; binary and
  * rgb derive from it.  Any output pointer may be NULL.  sem grid: palette[label16 of a

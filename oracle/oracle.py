@@ -358,3 +358,100 @@ def build_deformed_grid(voxel_grid, part_labels, saved_params, image_shape):
             continue
         out[cd[:, 2], cd[:, 1], cd[:, 0]] = cols
     return out
+
+
+# ---- N1/N2: component-guided carve, extrusion, recolouring, partwise_carve -----------------------------
+def label6(mask):
+    """scipy.ndimage.label(mask) (default 6-connected structure) -> (int32 labels, n)."""
+    m = np.ascontiguousarray(np.asarray(mask) != 0).view(np.uint8)
+    lab = np.zeros(m.shape, np.int32)
+    lib().orc_label6.restype = _i64
+    n = lib().orc_label6(_p(m), _i64(m.shape[0]), _i64(m.shape[1]), _i64(m.shape[2]), lab.ctypes.data_as(C.POINTER(C.c_int32)))
+    return lab, int(n)
+
+
+def left_right_guided_carve(colored_grid, semantic_mask, target_color, angle=60, visualize=False, stride=2):
+    """voxel_carving_utils.py:163-210 (prints included: they are part of the notebook output)."""
+    carved = colored_grid.copy()
+    mask2d = np.all(semantic_mask == target_color, axis=-1)
+    if not np.any(mask2d):
+        print(f"[SKIP] No mask for color {target_color}")
+        return carved
+    lab, n = label6(np.all(colored_grid == target_color, axis=-1))
+    print(f"[{target_color}] 3D components: {n}")
+    for i in range(1, n + 1):
+        m3 = lab == i
+        idx = np.argwhere(m3)
+        x0, y0, z0 = idx.min(axis=0)
+        x1, y1, z1 = idx.max(axis=0) + 1
+        print(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
+        crop2d = mask2d[y0:y1, x0:x1]
+        sub = colored_grid[x0:x1, y0:y1, z0:z1].copy()
+        occ = np.any(sub > 0, axis=-1).astype(np.uint8)
+        carved_occ = process_voxel_grid(occ, crop2d, angle)
+        print(f"    carved voxels: {np.count_nonzero(carved_occ)}")
+        cc = sub * carved_occ[:, :, :, None]
+        view = carved[x0:x1, y0:y1, z0:z1]
+        view[m3[x0:x1, y0:y1, z0:z1]] = 0
+        keep = np.any(cc > 0, axis=-1)
+        view[keep] = cc[keep]
+    return carved
+
+
+def extrude_from_surface(grid, mask_2d, axis, direction="+", depth=5, fill_color=None):
+    """voxel_carving_utils.py:213-248."""
+    occ = occupancy(grid)
+    W, H, D = occ.shape
+    filled = np.zeros(occ.shape, bool)
+    if axis == 2:
+        start = np.argmax(occ if direction == "+" else occ[:, :, ::-1], axis=2)
+        if direction == "-":
+            start = D - 1 - start
+        valid = np.asarray(mask_2d).T
+        for d in range(depth):
+            z = start + d if direction == "+" else start - d
+            ok = (z >= 0) & (z < D) & valid
+            xs, ys = np.nonzero(ok)
+            filled[xs, ys, z[xs, ys]] = True
+    elif axis == 0:
+        start = np.argmax(occ if direction == "+" else occ[::-1], axis=0)
+        if direction == "-":
+            start = W - 1 - start
+        valid = np.asarray(mask_2d)
+        for d in range(depth):
+            x = start + d if direction == "+" else start - d
+            ok = (x >= 0) & (x < W) & valid
+            ys, zs = np.nonzero(ok)
+            filled[x[ys, zs], ys, zs] = True
+    out = grid.copy()
+    out[filled] = 0 if fill_color is None else fill_color
+    return out
+
+
+def recolor_backward_components(voxel_grid, color, new_color, k=4, sort_axis=2):
+    """voxel_carving_utils.py:252-266."""
+    lab, n = label6(np.all(voxel_grid == color, axis=-1))
+    comps = [(i, np.argwhere(lab == i)[:, sort_axis].mean()) for i in range(1, n + 1)]
+    keep = {i for i, _ in sorted(comps, key=lambda t: t[1])[:k]}
+    out = voxel_grid.copy()
+    for i in range(1, n + 1):
+        if i not in keep:
+            out[lab == i] = new_color
+    return out
+
+
+def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_full, part_colors_np, group_jobs, part_symmetry,
+                   extrusion_depths, recolor_back_minarets=True, visualize=False, stride=4):
+    """voxel_carving_utils.py:302-400."""
+    grid = part_carve(colored_voxel_grid, semantic_mask_exterior, group_jobs)
+    for part, angle in part_symmetry.items():
+        grid = left_right_guided_carve(grid, semantic_mask_exterior, part_colors_np[part], angle=angle)
+    for part, depth in extrusion_depths.items():
+        mk = np.all(semantic_mask_full == part_colors_np[part], axis=-1)
+        for ax, dr in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
+            grid = extrude_from_surface(grid, mk, axis=ax, direction=dr, depth=depth, fill_color=part_colors_np[part])
+    if recolor_back_minarets:
+        oriented = np.flip(grid.transpose(2, 1, 0, 3), axis=1)
+        grid = recolor_backward_components(oriented, part_colors_np["front_minarets"], new_color=part_colors_np["back_minarets"],
+                                           k=2, sort_axis=0)
+    return grid

@@ -441,3 +441,37 @@ i64 orc_deform_coords(const float* pts, i64 n, double sxz, double sy, double kx,
         if (m == 0 || orc_cmp3(out + 3 * i, out + 3 * (m - 1)) != 0) { if (m != i) memcpy(out + 3 * m, out + 3 * i, 3 * sizeof(i64)); ++m; }
     return m;
 }
+
+/* ------------------------------------------------------------------------------------
+ * scipy.ndimage.label(mask) with the default 6-connected structure (call sites
+ * voxel_carving_utils.py:175, :254): labels 1..n in raster order of each component's first
+ * voxel.  Two-pass union-find with "smaller index is the root".
+ * ---------------------------------------------------------------------------------- */
+static i64 orc_uf_find(i64* p, i64 v) { while (p[v] != v) { p[v] = p[p[v]]; v = p[v]; } return v; }
+
+i64 orc_label6(const u8* mask, i64 A0, i64 A1, i64 A2, int32_t* labels) {
+    const i64 n = A0 * A1 * A2;
+    i64* p = (i64*)malloc((size_t)(n ? n : 1) * sizeof(i64));
+    if (!p) return -1;
+    for (i64 v = 0; v < n; ++v) p[v] = v;
+    for (i64 v = 0; v < n; ++v) {
+        if (!mask[v]) continue;
+        const i64 a2 = v % A2, a1 = (v / A2) % A1;
+        const i64 nb[3] = {a2 > 0 ? v - 1 : -1, a1 > 0 ? v - A2 : -1, v >= A1 * A2 ? v - A1 * A2 : -1};
+        for (int k = 0; k < 3; ++k) {
+            if (nb[k] < 0 || !mask[nb[k]]) continue;
+            i64 ra = orc_uf_find(p, v), rb = orc_uf_find(p, nb[k]);
+            if (ra == rb) continue;
+            if (ra < rb) p[rb] = ra; else p[ra] = rb;
+        }
+    }
+    i64 next = 0;
+    for (i64 v = 0; v < n; ++v) {
+        if (!mask[v]) { labels[v] = 0; continue; }
+        const i64 r = orc_uf_find(p, v);
+        if (r == v) labels[v] = (int32_t)(++next);      /* roots are met first in raster order */
+        else labels[v] = labels[r];
+    }
+    free(p);
+    return next;
+}

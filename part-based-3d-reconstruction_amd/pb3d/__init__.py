@@ -11,13 +11,15 @@ from .camera_geometry import look_at_rotation, project  # noqa: F401
 from .deformation_estimation import build_deformed_grid, deform_coords, deform_part, evaluate_part_deform  # noqa: F401
 from .config import INTERIOR_PARTS, MAX_DIM, PART_COLORS, PART_COLORS_NP  # noqa: F401
 from .projection_utils import project_colored_voxels  # noqa: F401
-from .voxel_carving_utils import (apply_colored_mask_to_voxel_grid, carve_voxel_grid_with_masks, global_carve,  # noqa: F401
-                                  part_carve, process_voxel_grid)
+from .voxel_carving_utils import (apply_colored_mask_to_voxel_grid, carve_voxel_grid_with_masks, extrude_from_surface,  # noqa: F401
+                                  global_carve, left_right_guided_carve, part_carve, partwise_carve, process_voxel_grid,
+                                  recolor_backward_components)
 from .voxel_utils import get_voxel_points_by_parts, voxel_grid_to_points  # noqa: F401
 
 _PATCH = {
     "voxel_carving_utils": ["carve_voxel_grid_with_masks", "process_voxel_grid", "apply_colored_mask_to_voxel_grid",
-                            "part_carve", "global_carve", "_occupancy"],
+                            "part_carve", "global_carve", "_occupancy", "left_right_guided_carve", "extrude_from_surface",
+                            "recolor_backward_components", "partwise_carve"],
     "voxel_utils": ["get_voxel_points_by_parts", "voxel_grid_to_points"],
     "projection_utils": ["project_colored_voxels"],
     "camera_estimation": ["compute_partwise_iou"],

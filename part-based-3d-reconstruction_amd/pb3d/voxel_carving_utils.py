@@ -13,7 +13,7 @@ from . import _lib
 from .config import PART_COLORS, PART_COLORS_NP  # noqa: F401  (re-exported like upstream)
 
 __all__ = ["carve_voxel_grid_with_masks", "process_voxel_grid", "apply_colored_mask_to_voxel_grid", "part_carve",
-           "global_carve"]
+           "left_right_guided_carve", "extrude_from_surface", "recolor_backward_components", "global_carve", "partwise_carve"]
 
 # optional visualisation hook (reference utils/visualization.plot_voxel); set by pb3d.install()
 plot_voxel = None
@@ -172,3 +172,186 @@ def global_carve(binary_mask, semantic_mask_exterior, angle_interval=90, stride=
         if pts.shape[0] > 0:
             plot_voxel(pts, cols, title="After global symmetric carving")
     return out
+
+
+# =====================================================================================================
+# Component-guided symmetry, interior extrusion, back-minaret recolouring, partwise_carve
+# (reference :163-266, :302-400).  Connected components are labelled on the device (csrc/components.hip).
+# =====================================================================================================
+def _color_u8(color):
+    """a palette entry as 3 uint8 values, or None if it cannot equal any uint8 voxel"""
+    c = np.asarray(color).reshape(-1)
+    if c.size != 3 or np.any(c < 0) or np.any(c > 255) or np.any(c != np.round(c)):
+        return None
+    return np.ascontiguousarray(c.astype(np.uint8))
+
+
+def _label(d_grid, shape3, color_u8, d_labels):
+    A0, A1, A2 = shape3
+    n = C.c_int64(0)
+    _lib.check(_lib.load().pb3d_label_color_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, _lib.p_u8(color_u8),
+                                                C.c_void_p(d_labels.ptr), C.byref(n)))
+    return n.value
+
+
+def _component_stats(d_labels, shape3, n):
+    A0, A1, A2 = shape3
+    bbox = np.zeros((max(n, 1), 6), np.int64); cnt = np.zeros(max(n, 1), np.int64); sums = np.zeros((max(n, 1), 3), np.int64)
+    if n:
+        _lib.check(_lib.load().pb3d_component_stats_dev(_lib.ctx(), C.c_void_p(d_labels.ptr), A0, A1, A2, n,
+                                                        bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
+                                                        sums.ctypes.data_as(_lib.i64p)))
+    return bbox[:n], cnt[:n], sums[:n]
+
+
+def left_right_guided_carve(colored_grid, semantic_mask, target_color, angle=60, visualize=False, stride=2):
+    """Per 3-D connected component of `target_color`: crop its bounding box, rotate-and-carve the crop's
+    occupancy with the part's own angle step against the cropped 2-D mask, clear the component and paste
+    what survives; reference :163-210 (prints kept: they are notebook output)."""
+    from . import device as dev
+    g = _lib.as_u8(colored_grid, "colored_grid")
+    if g.ndim != 4 or g.shape[3] != 3:
+        raise ValueError("not enough values to unpack (expected 4, got %d)" % g.ndim)
+    W, H, D, _ = g.shape
+    mask2d = np.all(np.asarray(semantic_mask) == target_color, axis=-1)
+    if not np.any(mask2d):
+        print(f"[SKIP] No mask for color {target_color}")
+        return g.copy()
+    lib, ctx = _lib.load(), _lib.ctx()
+    d_col = dev.from_numpy(g)
+    d_carved = dev.DeviceBuffer(g.size)
+    _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), g.size))
+    d_lab = dev.DeviceBuffer(W * H * D * 4)
+    bufs = [d_col, d_carved, d_lab]
+    try:
+        cu8 = _color_u8(target_color)
+        num = _label(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else 0
+        print(f"[{target_color}] 3D components: {num}")
+        bbox, _, _ = _component_stats(d_lab, (W, H, D), num)
+        for i in range(1, num + 1):
+            x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
+            print(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
+            Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
+            crop2d = mask2d[y0:y1, x0:x1]
+            m = _lib.truth_u8(_mask_to_wh(crop2d, Wc, Hc))
+            lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
+            nv = Wc * Hc * Dc
+            d_occ = dev.DeviceBuffer(nv); d_out = dev.DeviceBuffer(nv); d_tmp = dev.DeviceBuffer(nv); d_m = dev.from_numpy(m)
+            try:
+                _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
+                if isinstance(angle, (bool, np.bool_)) or not isinstance(angle, (int, np.integer)):
+                    raise TypeError(f"'{type(angle).__name__}' object cannot be interpreted as an integer")
+                if angle == 0:
+                    raise ValueError("range() arg 3 must not be zero")
+                if angle < 0:
+                    src = d_occ   # empty angle loop: the crop's occupancy is returned as is
+                else:
+                    dev.process_grid(d_occ, Wc, Hc, Dc, d_m, int(min(angle, 91)), d_out, d_tmp)
+                    src = d_out
+                cnt = C.c_int64(0)
+                _lib.check(lib.pb3d_points_count_dev(ctx, C.c_void_p(src.ptr), Wc, Hc, Dc, 1, None, 0, 1, C.byref(cnt)))
+                print(f"    carved voxels: {cnt.value}")
+                _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
+                                                        lo, hi, C.c_void_p(d_carved.ptr)))
+                dev.sync()
+            finally:
+                for b in (d_occ, d_out, d_tmp, d_m):
+                    b.free()
+        return d_carved.download(g.shape)
+    finally:
+        for b in bufs:
+            b.free()
+
+
+def extrude_from_surface(grid, mask_2d, axis, direction="+", depth=5, fill_color=None):
+    """From the first occupied voxel along `axis` (seen from the `direction` side) paint `depth` cells
+    where the 2-D mask allows; reference :213-248 (an empty column starts at index 0, like np.argmax)."""
+    from . import device as dev
+    g = _lib.as_u8(grid, "grid")
+    if g.ndim != 4 or g.shape[3] != 3:
+        raise ValueError("extrude_from_surface expects a (W,H,D,3) grid")
+    W, H, D, _ = g.shape
+    if axis not in (0, 2) or int(depth) <= 0:
+        return g.copy()
+    if direction not in ("+", "-"):
+        raise ValueError("direction must be '+' or '-'")
+    m = np.asarray(mask_2d)
+    if axis == 2:
+        valid = m.T
+        if valid.shape != (W, H):
+            raise ValueError(f"operands could not be broadcast together with shapes ({W},{H}) {valid.shape}")
+        vw = H
+    else:
+        valid = m
+        if valid.shape != (H, D):
+            raise ValueError(f"operands could not be broadcast together with shapes ({H},{D}) {valid.shape}")
+        vw = D
+    vt = _lib.truth_u8(valid)
+    fc = None if fill_color is None else np.ascontiguousarray(np.asarray(fill_color).astype(np.uint8).reshape(3))
+    d_in = dev.from_numpy(g); d_out = dev.DeviceBuffer(g.size); d_v = dev.from_numpy(vt)
+    try:
+        _lib.check(_lib.load().pb3d_extrude_dev(_lib.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_v.ptr), vw, int(axis),
+                                                1 if direction == "+" else 0, int(depth), None if fc is None else _lib.p_u8(fc),
+                                                C.c_void_p(d_out.ptr)))
+        return d_out.download(g.shape)
+    finally:
+        for b in (d_in, d_out, d_v):
+            b.free()
+
+
+def recolor_backward_components(voxel_grid, color, new_color, k=4, sort_axis=2):
+    """Keep the k components of `color` with the smallest mean coordinate on sort_axis, recolour the rest;
+    reference :252-266.  Returns a C-contiguous copy (the input is usually a transposed/flipped view)."""
+    from . import device as dev
+    g = np.ascontiguousarray(_lib.as_u8(voxel_grid, "voxel_grid"))
+    if g.ndim != 4 or g.shape[3] != 3:
+        raise ValueError("recolor_backward_components expects an (A0,A1,A2,3) grid")
+    A0, A1, A2, _ = g.shape
+    cu8 = _color_u8(color)
+    if cu8 is None or g.size == 0:
+        return g.copy()
+    d_g = dev.from_numpy(g); d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
+    try:
+        n = _label(d_g, (A0, A1, A2), cu8, d_lab)
+        if n == 0:
+            return g.copy()
+        _, cnt, sums = _component_stats(d_lab, (A0, A1, A2), n)
+        means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column
+        keep = {i for i, _ in sorted(means, key=lambda t: t[1])[:k]}
+        flags = np.array([0 if (i + 1) in keep else 1 for i in range(n)], np.uint8)
+        nc = np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
+        _lib.check(_lib.load().pb3d_recolor_components_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n,
+                                                           _lib.p_u8(nc), C.c_void_p(d_g.ptr)))
+        return d_g.download(g.shape)
+    finally:
+        d_g.free(); d_lab.free()
+
+
+def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_full, part_colors_np, group_jobs, part_symmetry,
+                   extrusion_depths, recolor_back_minarets=True, visualize=False, stride=4):
+    """Part-wise refinement after global carving; reference :302-400.  Returns (D,H,W,3) when the
+    back-minaret recolouring runs (transposed + flipped, as upstream), else (W,H,D,3)."""
+    def show(grid, title):
+        if visualize and plot_voxel is not None:
+            from .voxel_utils import voxel_grid_to_points
+            pts, cols, _ = voxel_grid_to_points(grid, stride=stride)
+            if pts.shape[0] > 0:
+                plot_voxel(pts, cols, title=title)
+
+    grid = part_carve(colored_voxel_grid, semantic_mask_exterior, group_jobs, visualize=False)
+    show(grid, "After part-wise symmetric carving (global symmetry on each part)")
+    for part, angle in part_symmetry.items():
+        grid = left_right_guided_carve(colored_grid=grid, semantic_mask=semantic_mask_exterior, target_color=part_colors_np[part],
+                                       angle=angle, visualize=False, stride=stride)
+    show(grid, "After part-wise symmetric carving (local symmetry on each part)")
+    for part, depth in extrusion_depths.items():
+        mask = np.all(np.asarray(semantic_mask_full) == part_colors_np[part], axis=-1)
+        for axis, direction in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
+            grid = extrude_from_surface(grid, mask, axis=axis, direction=direction, depth=depth, fill_color=part_colors_np[part])
+    show(grid, "After interior extrusion")
+    if recolor_back_minarets:
+        oriented = np.flip(grid.transpose(2, 1, 0, 3), axis=1)
+        grid = recolor_backward_components(oriented, part_colors_np["front_minarets"], new_color=part_colors_np["back_minarets"],
+                                           k=2, sort_axis=0)
+        show(grid, "After back-minaret recoloring")
+    return grid

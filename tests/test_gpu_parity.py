@@ -354,3 +354,67 @@ def test_deformation_loop_f8(pb3d_gpu, oracle, golden):
         assert np.array_equal(a, b)
     with pytest.raises(pb3d_gpu._lib.Pb3dError, match="voxel indices"):
         pb3d_gpu.deform_coords(np.array([[0.5, 1, 2]], np.float32), (10, 10), (4, 4, 4), dict(scale_y=1.0, shift_y=0.0, scale_xz=1.0, shift_xz=0.0))
+
+
+PART_SYMMETRY = {"dome": 5, "chhatris": 45, "front_minarets": 5, "small_minarets": 5}
+EXTRUSION = {"main_door": 20, "windows": 10}
+
+
+def test_connected_components_device(pb3d_gpu, golden, oracle):
+    """device union-find labelling == scipy.ndimage.label numbering (fixture) incl. 590 salt-noise components."""
+    from pb3d import device as dev
+    from pb3d.voxel_carving_utils import _component_stats, _label
+    g = golden("f5_label_noise")
+    grid = np.ascontiguousarray(g["grid"]); A0, A1, A2, _ = grid.shape
+    d_g = dev.from_numpy(grid); d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
+    n = _label(d_g, (A0, A1, A2), np.array(pb3d_gpu.PART_COLORS["dome"], np.uint8), d_lab)
+    lab = d_lab.download((A0, A1, A2), np.int32)
+    assert n == int(g["n"]) and np.array_equal(lab, g["labels"])
+    bbox, cnt, sums = _component_stats(d_lab, (A0, A1, A2), n)
+    for i in (1, 2, n // 2, n):
+        idx = np.argwhere(g["labels"] == i)
+        assert np.array_equal(bbox[i - 1], np.concatenate([idx.min(0), idx.max(0) + 1])) and cnt[i - 1] == len(idx)
+        assert np.array_equal(sums[i - 1], idx.sum(0))
+    # one big snake-like component and an empty selection
+    snake = np.zeros((40, 30, 50), bool); snake[::2] = True; snake[1::4, 0] = True; snake[3::4, -1] = True
+    col = np.zeros(snake.shape + (3,), np.uint8); col[snake] = (9, 9, 9)
+    d2 = dev.from_numpy(col); l2 = dev.DeviceBuffer(snake.size * 4)
+    n2 = _label(d2, snake.shape, np.array((9, 9, 9), np.uint8), l2)
+    want, nw = oracle.label6(snake)
+    assert n2 == nw == 1 and np.array_equal(l2.download(snake.shape, np.int32), want)
+    assert _label(d2, snake.shape, np.array((1, 2, 3), np.uint8), l2) == 0
+    for b in (d_g, d_lab, d2, l2):
+        b.free()
+
+
+@pytest.mark.parametrize("name", ["Taj_96", "Akbar_64", "Bibi_80"])
+def test_partwise_stages_f5(pb3d_gpu, golden, name):
+    """N1/N2: component-guided carve (incl. its printed log), extrusion, recolouring and the whole partwise_carve
+    against the reference's stage outputs."""
+    import contextlib
+    import io
+    g = golden(f"f5_{name}")
+    meta = json.load(open(os.path.join(GOLDEN, "f5_meta.json")))[name]
+    PCN = pb3d_gpu.PART_COLORS_NP
+    gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90)
+    pc = pb3d_gpu.part_carve(gc, g["ext"], JOBS_NB1)
+    grid = pc
+    for (part, angle), want_log in zip(PART_SYMMETRY.items(), meta["lrgc_stdout"]):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            grid = pb3d_gpu.left_right_guided_carve(grid, g["ext"], PCN[part], angle=angle)
+        assert sha(grid) == meta["stages"][f"lrgc_{part}"], part
+        assert buf.getvalue() == want_log
+    for part, depth in EXTRUSION.items():
+        mk = np.all(g["sem"] == PCN[part], axis=-1)
+        for ax, dr in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
+            grid = pb3d_gpu.extrude_from_surface(grid, mk, axis=ax, direction=dr, depth=depth, fill_color=PCN[part])
+            assert sha(grid) == meta["stages"][f"extrude_{part}_{ax}{dr}"], (part, ax, dr)
+    oriented = np.flip(grid.transpose(2, 1, 0, 3), axis=1)
+    rec = pb3d_gpu.recolor_backward_components(oriented, PCN["front_minarets"], new_color=PCN["back_minarets"], k=2, sort_axis=0)
+    assert np.array_equal(rec, g["after_recolor"]) and rec.flags["C_CONTIGUOUS"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = pb3d_gpu.partwise_carve(gc, g["ext"], g["sem"], PCN, JOBS_NB1, PART_SYMMETRY, EXTRUSION)
+    assert sha(full) == meta["partwise_sha256"] and list(full.shape) == meta["partwise_shape"]
+    assert np.array_equal(pb3d_gpu.extrude_from_surface(pc, np.all(g["sem"] == PCN["full_building"], axis=-1), 2, "-", 3, None), g["extrude_none"])
+    assert np.array_equal(pb3d_gpu.recolor_backward_components(pc, PCN["front_minarets"], PCN["windows"], k=1, sort_axis=2), g["recolor_k1_axis2"])

@@ -83,12 +83,12 @@ def test_install_patches_a_utils_like_package():
     import types
     import pb3d
     pkg = types.ModuleType("fakeutils"); sub = types.ModuleType("fakeutils.voxel_carving_utils")
-    sub.process_voxel_grid = lambda *a: "old"; sub.left_right_guided_carve = lambda *a: "kept"
+    sub.process_voxel_grid = lambda *a: "old"; sub.launch_smart_aligner = lambda *a: "kept"
     pkg.process_voxel_grid = sub.process_voxel_grid
     sys.modules["fakeutils"] = pkg; sys.modules["fakeutils.voxel_carving_utils"] = sub
     try:
         patched = pb3d.install(pkg)
         assert ("fakeutils.voxel_carving_utils", "process_voxel_grid") in patched and ("fakeutils", "process_voxel_grid") in patched
-        assert sub.process_voxel_grid is pb3d.process_voxel_grid and sub.left_right_guided_carve() == "kept"
+        assert sub.process_voxel_grid is pb3d.process_voxel_grid and sub.launch_smart_aligner() == "kept"
     finally:
         del sys.modules["fakeutils"], sys.modules["fakeutils.voxel_carving_utils"]

@@ -208,3 +208,53 @@ def test_deformation_closures_f8(oracle, golden):
         saved[part] = {"deform": c["deform"], "iou": iou}
     full = oracle.build_deformed_grid(grid, PC, saved, meta["image_shape"])
     assert sha(full) == meta["deformed_grid_sha256"] and np.array_equal(full, g["deformed_grid"])
+
+
+GROUP_JOBS = JOBS_NB1
+PART_SYMMETRY = {"dome": 5, "chhatris": 45, "front_minarets": 5, "small_minarets": 5}
+EXTRUSION = {"main_door": 20, "windows": 10}
+
+
+def _pcn(orc):
+    return {k: np.array(v) for k, v in orc.PART_COLORS.items()}
+
+
+def test_label6_matches_scipy_fixture(oracle, golden):
+    g = golden("f5_label_noise")
+    lab, n = oracle.label6(np.all(g["grid"] == np.array(oracle.PART_COLORS["dome"]), axis=-1))
+    assert n == int(g["n"]) and np.array_equal(lab, g["labels"])
+
+
+@pytest.mark.parametrize("name", ["Taj_96", "Akbar_64", "Bibi_80"])
+def test_partwise_stages_f5(oracle, golden, name, capsys):
+    import contextlib
+    import io
+    g = golden(f"f5_{name}")
+    meta = json.load(open(os.path.join(GOLDEN, "f5_meta.json")))[name]
+    PCN = _pcn(oracle)
+    gc = oracle.global_carve(g["binary"], g["ext"], 90)
+    pc = oracle.part_carve(gc, g["ext"], GROUP_JOBS)
+    for part in ("front_minarets", "full_building"):
+        lab, n = oracle.label6(np.all(pc == PCN[part], axis=-1))
+        assert n == meta[f"label_{part}"]["n"] and sha(lab) == meta[f"label_{part}"]["sha256"]
+    grid = pc
+    for (part, angle), want_log in zip(PART_SYMMETRY.items(), meta["lrgc_stdout"]):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            grid = oracle.left_right_guided_carve(grid, g["ext"], PCN[part], angle=angle)
+        assert sha(grid) == meta["stages"][f"lrgc_{part}"], part
+        assert buf.getvalue() == want_log
+    assert np.array_equal(grid, g["after_lrgc"])
+    for part, depth in EXTRUSION.items():
+        mk = np.all(g["sem"] == PCN[part], axis=-1)
+        for ax, dr in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
+            grid = oracle.extrude_from_surface(grid, mk, axis=ax, direction=dr, depth=depth, fill_color=PCN[part])
+            assert sha(grid) == meta["stages"][f"extrude_{part}_{ax}{dr}"], (part, ax, dr)
+    oriented = np.flip(grid.transpose(2, 1, 0, 3), axis=1)
+    rec = oracle.recolor_backward_components(oriented, PCN["front_minarets"], new_color=PCN["back_minarets"], k=2, sort_axis=0)
+    assert np.array_equal(rec, g["after_recolor"]) and rec.flags["C_CONTIGUOUS"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = oracle.partwise_carve(gc, g["ext"], g["sem"], PCN, GROUP_JOBS, PART_SYMMETRY, EXTRUSION)
+    assert sha(full) == meta["partwise_sha256"] and list(full.shape) == meta["partwise_shape"]
+    assert np.array_equal(oracle.extrude_from_surface(pc, np.all(g["sem"] == PCN["full_building"], axis=-1), 2, "-", 3, None), g["extrude_none"])
+    assert np.array_equal(oracle.recolor_backward_components(pc, PCN["front_minarets"], PCN["windows"], k=1, sort_axis=2), g["recolor_k1_axis2"])
