@@ -97,7 +97,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    os.environ["PB3D_DEVICE"] = str(local_rank)
+    # PB3D_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a 1-GPU box (all ranks on GPU 0, no RCCL)
+    one_device = os.environ.get("PB3D_BENCH_ONE_DEVICE") == "1"
+    os.environ["PB3D_DEVICE"] = "0" if one_device else str(local_rank)
+    if one_device:
+        args.no_allgather = True
 
     import pb3d
     from pb3d import device as dev
@@ -146,7 +150,7 @@ def main():
     value = total_vox * args.steps / t / 1e6
     achieved = ALG_BYTES_PER_VOXEL * slab_vox / (kernel_ms * 1e-3) / 1e9
     out = {
-        "metric": "Mvoxel/s carved (semantic carve, 1024^3 grid)", "value": round(value, 1), "unit": "Mvoxel/s",
+        "metric": f"Mvoxel/s carved (semantic carve, {S}^3 grid)", "value": round(value, 1), "unit": "Mvoxel/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"configs[3]: synthetic 16-label mask, {S}^3 semantic RGB grid, op M1 "

@@ -287,6 +287,10 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
                  "pb3d_part_carve: null buffer");
     for (int j = 0; j < njobs; ++j)
         PB3D_REQUIRE(job_skip[j] || job_angle[j] > 0, "pb3d_part_carve: job %d has angle %d (must be > 0)", j, job_angle[j]);
+    {   // all jobs 90 degrees on a grid the tiled transpose handles: one fused sweep (csrc/rotate_tiled.hip, K5)
+        const int rc = pb3d_try_part_carve90(ctx, d_colored, W, H, D, d_mask_sub, d_mask_carve, job_angle, job_skip, njobs, d_out);
+        if (rc != PB3D_EUNSUPPORTED) return rc;
+    }
     void *occ, *carved, *tmp, *keep;
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &occ));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));

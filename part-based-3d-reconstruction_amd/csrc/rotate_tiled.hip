@@ -312,6 +312,141 @@ __global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K5: part_carve with 90-degree jobs, all jobs in ONE sweep.  Every job writes colored[v] itself where
+// it keeps (reference :152-158), so the overlay is the union of the jobs' keep sets:
+//   keep[x,y,z] = valid(x,z) && occ[c0 - z, y, x + c2] && (A[x,y] & A[c0 - z, y]) != 0
+// with occ = any(colored > 0) and A[x,y] = bitset over jobs of (mask_sub_j && mask_carve_j)[x,y]
+// (both the source-side and the destination-side carve of a job use its own masks).
+// Phase A is k_rot90's register transpose of the occupancy tile and produces 16 keep bits per
+// (row, 16-z run) into LDS; phase B re-maps the threads so that each 16-byte piece of an output row is
+// loaded from `colored`, masked (alignbyte patterns at the piece's RGB phase) and stored with 128
+// contiguous bytes per 8 lanes.  Rows whose keep bits are all zero are never read.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, const u8* __restrict__ occ, const u32* __restrict__ A,
+                                                const u32* __restrict__ vbits, int nw, int c0, int c2, i64 W, i64 H, i64 D, int TY,
+                                                u8* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
+    __shared__ u32 asrc[128];
+    __shared__ __attribute__((aligned(8))) unsigned short keepb[128 * 8 + 4];
+    const int tid = threadIdx.x;
+    const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;
+    const i64 y_beg = (i64)blockIdx.z * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    const int cb = tid & 7;
+    const i64 rbase = (i64)c0 - (z0 + 127);
+    const i64 scol = x0 + c2 + 16 * cb;
+    const bool col_ok = scol >= 0 && scol + 15 < D;
+    const int zg = tid & 7, xg = tid >> 3;
+    const int g = 7 - zg;
+    const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
+    const i64 zo = z0 + 16 * zg;
+    u32 vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 x = x0 + 4 * xg + i;
+        vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
+    }
+    const i64 row_bytes = ((D - z0 < 128 ? D - z0 : 128)) * 3;   // bytes of one output row inside this tile
+    u32x4 stg[4];
+    u32 stg_a = 0;
+    auto load_plane = [&](i64 y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 n0 = rbase + (tid >> 3) + 32 * j;
+            stg[j] = (u32x4)(0u);
+            if (col_ok && n0 >= 0 && n0 < W) stg[j] = *(const u32x4*)(occ + (n0 * H + y) * D + scol);
+        }
+        if (tid < 128) {
+            const i64 n0 = rbase + tid;
+            stg_a = (n0 >= 0 && n0 < W) ? A[n0 * H + y] : 0u;
+        }
+    };
+    load_plane(y_beg);
+    for (i64 y = y_beg; y < y_end; ++y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 3) + 32 * j;
+            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = stg[j];
+        }
+        if (tid < 128) asrc[tid] = stg_a;
+        __syncthreads();
+        if (y + 1 < y_end) load_plane(y + 1);
+        // ---- phase A: keep bits of this thread's 4 rows x 16 z
+        u32 d[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
+        u32 srcok[4] = {0, 0, 0, 0};   // per row i: bit q set iff occupancy byte non-zero ... filled below
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            u32 k16 = 0;
+            if (x < W && vb[i]) {
+                const u32 adst = A[x * H + y];
+                if (adst) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const u32 ob = (d[15 - q] >> (8 * i)) & 0xffu;               // occ[c0 - z, y, x + c2]
+                        const u32 as = asrc[16 * g + 15 - q];
+                        if (ob && (as & adst)) k16 |= 1u << q;
+                    }
+                    k16 &= vb[i];
+                }
+            }
+            srcok[i] = k16;
+            keepb[(4 * xg + i) * 8 + zg] = (unsigned short)k16;
+        }
+        __syncthreads();
+        // ---- phase B: row r = (tid >> 3) + 32 j, pieces pl, pl + 8, pl + 16 of its 384 bytes
+        const int pl = tid & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (tid >> 3) + 32 * j;
+            const i64 x = x0 + r;
+            if (x >= W) continue;
+            const u8* srow = colored + ((x * H + y) * D + z0) * 3;
+            u8* drow = out + ((x * H + y) * D + z0) * 3;
+            const unsigned short* kb = keepb + r * 8;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int pc = pl + 8 * kk;
+                if ((i64)16 * pc + 16 > row_bytes) continue;
+                const int v0 = (16 * pc) / 3;
+                const u32 ph = (u32)(pc % 3);
+                const int wi = v0 >> 4;
+                const u32 win = (u32)kb[wi] | ((wi < 7 ? (u32)kb[wi + 1] : 0u) << 16);
+                const u32 kb6 = (win >> (v0 & 15)) & 0x3fu;
+                u32x4 val = (u32x4)(0u);
+                if (kb6) {
+                    const u32x4 src = *(const u32x4*)(srow + 16 * pc);
+                    u32 m[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
+                    const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
+                              w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
+                              w4 = m[5] & 0x0000ffffu;
+                    val.x = src.x & __builtin_amdgcn_alignbyte(w1, w0, ph);
+                    val.y = src.y & __builtin_amdgcn_alignbyte(w2, w1, ph);
+                    val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
+                    val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
+                }
+                __builtin_nontemporal_store(val, (u32x4*)(drow + 16 * pc));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_sub, const u8* __restrict__ mask_carve,
+                                                    const int* __restrict__ job_on, int nj, i64 npix, u32* __restrict__ A) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (i64)gridDim.x * blockDim.x) {
+        u32 a = 0;
+        for (int j = 0; j < nj; ++j)
+            if (job_on[j] && mask_sub[(i64)j * npix + i] && mask_carve[(i64)j * npix + i]) a |= 1u << j;
+        A[i] = a;
+    }
+}
+
 }  // namespace
 
 // true when the (x,z) part of (M, off) is a signed permutation up to 2^-40 with an offset within
@@ -405,6 +540,52 @@ int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rg
     else
         hipLaunchKernelGGL(k_global_carve90b<TYC>, grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
                            (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+// All-90-degree part_carve in one sweep (K5).  Returns PB3D_EUNSUPPORTED (without an error message of
+// its own) when the fast-path conditions do not hold; the caller then runs the per-job pipeline.
+int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
+                          const int* job_angle, const int* job_skip, int njobs, u8* d_out) {
+    if (njobs > 32 || njobs <= 0) return PB3D_EUNSUPPORTED;
+    bool any = false;
+    for (int j = 0; j < njobs; ++j) {
+        if (job_skip[j]) continue;
+        if (job_angle[j] != 90) return PB3D_EUNSUPPORTED;
+        any = true;
+    }
+    if (!any) return PB3D_EUNSUPPORTED;
+    const i64 shape[3] = {W, H, D};
+    double M[9], off[3];
+    PB3D_TRY(pb3d_rotinv(90, M));
+    PB3D_TRY(pb3d_offset(M, shape, off));
+    if (!pb3d_is_perm_step(M, off, W, D)) return PB3D_EUNSUPPORTED;
+    const PermMap pm = perm_map(M, off);
+    const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
+    if (!(rot90 && D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_colored | (uintptr_t)d_out) & 15u) == 0 && W <= 65535 && H <= 65535))
+        return PB3D_EUNSUPPORTED;
+    RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    u32* bits; int nw;
+    PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
+    void *occ, *A, *jon;
+    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)(W * H * D), &occ));
+    PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)(W * H) * sizeof(u32), &A));
+    PB3D_TRY(pb3d_scratch(ctx, 6, 64 * sizeof(int), &jon));
+    int on[32];
+    for (int j = 0; j < 32; ++j) on[j] = (j < njobs && !job_skip[j]) ? 1 : 0;
+    PB3D_HIP(hipMemcpyAsync(jon, on, sizeof(on), hipMemcpyHostToDevice, ctx->stream));
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));   // `on` lives on this stack frame
+    hipLaunchKernelGGL(k_job_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, d_mask_carve,
+                       (const int*)jon, njobs, W * H, (u32*)A);
+    PB3D_CHECK_LAUNCH();
+    PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
+    int TY = 32;
+    const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
+    while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
+    dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
+    hipLaunchKernelGGL(k_part90, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw, pm.c0,
+                       pm.c2, W, H, D, TY, d_out);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

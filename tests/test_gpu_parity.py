@@ -418,3 +418,25 @@ def test_partwise_stages_f5(pb3d_gpu, golden, name):
     assert sha(full) == meta["partwise_sha256"] and list(full.shape) == meta["partwise_shape"]
     assert np.array_equal(pb3d_gpu.extrude_from_surface(pc, np.all(g["sem"] == PCN["full_building"], axis=-1), 2, "-", 3, None), g["extrude_none"])
     assert np.array_equal(pb3d_gpu.recolor_backward_components(pc, PCN["front_minarets"], PCN["windows"], k=1, sort_axis=2), g["recolor_k1_axis2"])
+
+
+def test_rccl_allgather_single_rank(pb3d_gpu):
+    """the RCCL path (dlopen, unique id, communicator, ncclAllGather on the context stream) with a 1-rank communicator:
+    the in-place gather of the only slab must leave the volume untouched and a separate send buffer must be copied."""
+    from pb3d import device as dev, dist
+    rng = np.random.default_rng(37)
+    slab = rng.integers(0, 256, (8, 16, 16, 3), dtype=np.uint8)
+    d_full = dev.from_numpy(slab)
+    uid = dist.new_unique_id()
+    assert uid.shape == (128,) and uid.any()
+    dist.comm_init(uid, 0, 1)
+    try:
+        dist.allgather(d_full, d_full, slab.nbytes)           # in place
+        dev.sync()
+        assert np.array_equal(d_full.download(slab.shape), slab)
+        d_dst = dev.DeviceBuffer(slab.nbytes); d_dst.zero()
+        dist.allgather(d_full, d_dst, slab.nbytes)
+        dev.sync()
+        assert np.array_equal(d_dst.download(slab.shape), slab)
+    finally:
+        dist.comm_destroy()

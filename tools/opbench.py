@@ -8,6 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "part-based-3d-reconstruction_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C  # noqa: E402
 
 import numpy as np  # noqa: E402
@@ -68,11 +69,62 @@ def main():
         for ang in (45, 5):
             L.check(lib.pb3d_rotinv(ang, L.p_dbl(M))); L.check(lib.pb3d_offset(L.p_dbl(M), (C.c_int64 * 3)(S, S, S), L.p_dbl(off)))
             report("M4", f"one rotate+carve step, {ang} deg", timeit(lambda: dev.rotate_carve(d_occ, S, S, S, M, off, d_mwh, d_o1), a.reps), 2)
-    if "M5" in ops:
-        d_out = dev.DeviceBuffer(nvox * 3)
-        report("M5", "global_carve(binary,rgb,90)", timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, 90, d_out), a.reps), 3)
-        d_out.free()
     d_occ.free(); d_o1.free(); d_tmp.free()
+    d_col = None
+    if any(o in ops for o in ("M5", "M6", "M7", "M8")):
+        d_col = dev.DeviceBuffer(nvox * 3)
+        ms = timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col), a.reps)
+        if "M5" in ops:
+            report("M5", "global_carve(binary,rgb,90)", ms, 3)
+    if "M6" in ops:
+        # six 90-degree part jobs of notebook 1 on the structured grid (labels 1..9 of the synthetic mask are the part colours)
+        import synth_host
+        lab, binary, rgb = synth_host.mask16(S)
+        names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
+        msub = np.zeros((len(names), S, S), np.uint8)
+        for j, nm in enumerate(names):
+            msub[j] = np.all(rgb == np.array(pb3d.PART_COLORS[nm], np.uint8), axis=-1).T
+        mcarve = np.ascontiguousarray(msub.transpose(0, 2, 1))      # W == H: _mask_to_wh transposes again
+        d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve); d_out = dev.DeviceBuffer(nvox * 3)
+        ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*[0 if msub[j].any() else 1 for j in range(6)])
+        fn = lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr),
+                                                      ang, skip, 6, C.c_void_p(d_out.ptr)))
+        ms = timeit(fn, max(2, a.reps // 2), warm=1)
+        report("M6", "part_carve, six 90-degree jobs", ms, 36, {"jobs": 6, "ms_per_job": round(ms / 6, 4)})
+        for b in (d_ms, d_mc, d_out):
+            b.free()
+    if "M7" in ops or "M8" in ops:
+        cols = np.ascontiguousarray(np.array(list(pb3d.PART_COLORS.values()), np.uint8))
+        n = C.c_int64(0)
+        cnt = lambda: L.check(lib.pb3d_points_count_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), 1, C.byref(n)))
+        cnt()
+        npts = n.value
+        d_pts = dev.DeviceBuffer(max(1, npts) * 12); d_pc = dev.DeviceBuffer(max(1, npts) * 3)
+        fill = lambda: L.check(lib.pb3d_points_fill_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), 1, npts,
+                                                        C.c_void_p(d_pts.ptr), C.c_void_p(d_pc.ptr)))
+        def both():
+            cnt(); fill()
+        ms = timeit(both, max(2, a.reps // 2), warm=1)
+        fillfrac = npts / nvox
+        if "M7" in ops:
+            report("M7", "get_voxel_points_by_parts (10 parts): count + fill", ms, round(3 + 15 * fillfrac, 3), {"points": npts, "fill": round(fillfrac, 4)})
+        if "M8" in ops and npts:
+            from pb3d.camera_geometry import look_at_rotation
+            cam = np.array([S / 2, S / 2, -2.5 * S], np.float32); tgt = np.array([S / 2, S / 2, S / 2], np.float32)
+            R = np.ascontiguousarray(look_at_rotation(cam, tgt), np.float64); cd = np.ascontiguousarray(cam, np.float64)
+            Hi = Wi = S
+            d_img = dev.DeviceBuffer(Hi * Wi * 3)
+            prec = (C.c_int * 4)(0, 0, 0, 0)
+            fn = lambda: L.check(lib.pb3d_project_dev(L.ctx(), C.c_void_p(d_pts.ptr), 0, C.c_void_p(d_pc.ptr), npts, L.p_dbl(R), L.p_dbl(cd),
+                                                      float(1.2 * S), S / 2.0, S / 2.0, prec, Hi, Wi, C.c_void_p(d_img.ptr)))
+            ms = timeit(fn, max(2, a.reps // 2), warm=1)
+            r = {"op": "M8", "name": "project_colored_voxels (f32 camera)", "size": S, "ms": round(ms, 4), "points": npts,
+                 "Mpts_s": round(npts / ms / 1e3, 1), "alg_B_per_point": 15, "alg_GB_s": round(15 * npts / ms / 1e6, 1)}
+            print(json.dumps(r), flush=True)
+            d_img.free()
+        d_pts.free(); d_pc.free()
+    if d_col is not None:
+        d_col.free()
     return res
 
 
