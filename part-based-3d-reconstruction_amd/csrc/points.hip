@@ -16,6 +16,7 @@ struct SelParams {
     i64 L1, L2, nlat;  // lattice dims ([::s]) and total lattice voxels
     int C, ncolors, stride;
     u8 colors[3 * 32];
+    u32 colors32[32];   // the same colours packed r | g << 8 | b << 16
 };
 
 __device__ __forceinline__ i64 lattice_to_voxel(const SelParams& p, i64 li, i64* i0, i64* i1, i64* i2) {
@@ -125,6 +126,105 @@ __global__ __launch_bounds__(256) void k_points_fill(const u8* __restrict__ grid
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stride == 1, RGB grids: 16 consecutive voxels per thread (48 bytes as three 16-byte loads), so a
+// block still covers kBlockVox = 4096 voxels in lattice order and shares the block-count scan with the
+// generic kernels.  In-block order = thread order (thread t owns voxels 16t .. 16t+15).
+// ------------------------------------------------------------------------------------------------
+typedef u32 u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32 select16(const SelParams& p, const u8* __restrict__ grid, i64 v0, i64 nvox, u32 w[12]) {
+    // loads the 48 bytes of voxels v0..v0+15 (bounds-checked at the grid's end) and returns their 16 select bits
+    if (v0 + 16 <= nvox) {
+        const u32x4v* g = (const u32x4v*)(grid + 3 * v0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const u32x4v t = g[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            u32 t = 0;
+            for (int b = 0; b < 4; ++b) { const i64 o = 3 * v0 + 4 * k + b; if (o < 3 * nvox) t |= (u32)grid[o] << (8 * b); }
+            w[k] = t;
+        }
+    }
+    u32 vox[16];   // r | g << 8 | b << 16
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+        vox[i] = __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) & 0x00ffffffu;
+    }
+    u32 bits = 0;
+    if (p.ncolors > 0) {
+        for (int k = 0; k < p.ncolors; ++k) {
+            const u32 ck = p.colors32[k];   // wave-uniform: one scalar load per colour for all 16 voxels
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bits |= (u32)(vox[i] == ck) << i;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bits |= (u32)(vox[i] != 0u) << i;
+    }
+    const i64 left = nvox - v0;
+    if (left < 16) bits &= (1u << left) - 1u;
+    return bits;
+}
+
+__global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ grid, SelParams p, u32* __restrict__ block_counts) {
+    __shared__ u32 wsum[4];
+    const i64 v0 = (i64)blockIdx.x * kBlockVox + 16 * threadIdx.x;
+    u32 w[12];
+    u32 c = v0 < p.nlat ? (u32)__popc(select16(p, grid, v0, p.nlat, w)) : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Phase 1: every thread ranks its selected voxels inside the block and drops (local index, colour) into LDS
+// in output order.  Phase 2: the block writes the compacted records with fully coalesced stores (dword j of
+// the points = component j % 3 of point j / 3; colour bytes linear).
+__global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
+                                                       float* __restrict__ pts, u8* __restrict__ cols) {
+    __shared__ u32 wsum[4];
+    __shared__ unsigned short lidx[kBlockVox];
+    __shared__ u8 lcol[kBlockVox * 3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const i64 base = (i64)blockIdx.x * kBlockVox;
+    const i64 v0 = base + 16 * threadIdx.x;
+    u32 w[12];
+    const u32 bits = v0 < p.nlat ? select16(p, grid, v0, p.nlat, w) : 0u;
+    const u32 c = (u32)__popc(bits);
+    u32 inc = c;
+    for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 k = inc - c;
+    for (int q = 0; q < wv; ++q) k += wsum[q];
+    const u32 total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if ((bits >> i) & 1u) {
+            lidx[k] = (unsigned short)(16 * threadIdx.x + i);
+            lcol[3 * k] = (u8)((w[(3 * i) >> 2] >> (((3 * i) & 3) * 8)) & 0xffu);
+            lcol[3 * k + 1] = (u8)((w[(3 * i + 1) >> 2] >> (((3 * i + 1) & 3) * 8)) & 0xffu);
+            lcol[3 * k + 2] = (u8)((w[(3 * i + 2) >> 2] >> (((3 * i + 2) & 3) * 8)) & 0xffu);
+            ++k;
+        }
+    }
+    __syncthreads();
+    const i64 out0 = block_off[blockIdx.x];
+    float* po = pts + 3 * out0;
+    for (u32 j = threadIdx.x; j < 3 * total; j += 256) {
+        const u32 pt = j / 3, comp = j - 3 * pt;
+        const i64 li = base + lidx[pt];
+        const i64 a2 = li % p.A2, r = li / p.A2;
+        const i64 val = comp == 0 ? a2 : (comp == 1 ? r % p.A1 : r / p.A1);
+        po[j] = (float)val;
+    }
+    u8* co = cols + 3 * out0;
+    for (u32 j = threadIdx.x; j < 3 * total; j += 256) co[j] = lcol[j];
+}
+
 int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, int stride, SelParams* p) {
     PB3D_REQUIRE(A0 >= 0 && A1 >= 0 && A2 >= 0 && (C == 1 || C == 3), "pb3d_points: bad shape (%lld,%lld,%lld,%d)",
                  (long long)A0, (long long)A1, (long long)A2, C);
@@ -138,6 +238,8 @@ int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, in
     p->C = C; p->ncolors = ncolors; p->stride = stride;
     memset(p->colors, 0, sizeof(p->colors));
     if (ncolors) memcpy(p->colors, colors, (size_t)3 * ncolors);
+    for (int k = 0; k < 32; ++k)
+        p->colors32[k] = k < ncolors ? ((u32)colors[3 * k] | ((u32)colors[3 * k + 1] << 8) | ((u32)colors[3 * k + 2] << 16)) : 0xffffffffu;
     return PB3D_OK;
 }
 
@@ -158,7 +260,9 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
     void *counts, *offsets;
     PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)nb * sizeof(u32), &counts));
     PB3D_TRY(pb3d_scratch(ctx, 9, (size_t)(nb + 1) * sizeof(i64), &offsets));
-    hipLaunchKernelGGL(k_points_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
+    const bool fast16 = stride == 1 && C == 3 && (((uintptr_t)d_grid) & 15u) == 0;
+    if (fast16) hipLaunchKernelGGL(k_points_count16, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
+    else hipLaunchKernelGGL(k_points_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
     PB3D_CHECK_LAUNCH();
     i64* total = (i64*)offsets + nb;
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)counts, (i64*)offsets, nb, total);
@@ -181,8 +285,13 @@ int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64
     const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
     PB3D_REQUIRE(ctx->scratch[9] && ctx->scratch_bytes[9] >= (size_t)(nb + 1) * sizeof(i64),
                  "pb3d_points_fill: call pb3d_points_count first");
-    hipLaunchKernelGGL(k_points_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9],
-                       d_pts, d_cols);
+    const bool fast16 = stride == 1 && C == 3 && (((uintptr_t)d_grid) & 15u) == 0;
+    if (fast16)
+        hipLaunchKernelGGL(k_points_fill16, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
+                           d_cols);
+    else
+        hipLaunchKernelGGL(k_points_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
+                           d_cols);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

@@ -56,11 +56,18 @@ __device__ __forceinline__ bool project_point(const ProjParams& P, const void* _
     return true;
 }
 
+// Points are visited from the LAST index down: the winner of a pixel is its largest point index, so once the
+// high indices have claimed their pixels the remaining points mostly lose on a plain read and skip the atomic.
 __global__ __launch_bounds__(256) void k_project_points(const void* __restrict__ pts, i64 n, ProjParams P,
                                                         u32* __restrict__ winner) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i64 i = n - 1 - t;
         int ui, vi;
-        if (project_point(P, pts, i, &ui, &vi)) atomicMax(&winner[(i64)vi * P.Wimg + ui], (u32)(i + 1));
+        if (project_point(P, pts, i, &ui, &vi)) {
+            u32* w = &winner[(i64)vi * P.Wimg + ui];
+            const u32 mine = (u32)(i + 1);
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(w, mine);
+        }
     }
 }
 
