@@ -155,6 +155,17 @@ int pb3d_project(pb3d_ctx* ctx, const void* pts, int pts_f64, const uint8_t* col
                  const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4],
                  int Himg, int Wimg, uint8_t* img);
 
+/* ---- z-buffer visibility (row N5), reference utils/eval_helpers_intra.py:134-190 -------------------------
+ * Same pinhole arithmetic as pb3d_project, but points with Z <= 1e-6 are dropped (no clamp).
+ * depth_buffer: zbuf[v,u] = min Z of the points landing on the pixel as float32, +inf where none (:134-163).
+ * visible_mask: mask[v,u] = 1 where some point has |Z - zbuf[v,u]| < eps (:168-190); eps_f32 != 0 when the
+ * comparison is made in float32 (float32 camera and a Python-float eps). */
+int pb3d_depth_buffer_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, int64_t n, const double R[9], const double cam[3], double f,
+                          double cx, double cy, const int prec[4], int Himg, int Wimg, float* d_zbuf);
+int pb3d_visible_mask_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, int64_t n, const double R[9], const double cam[3], double f,
+                          double cx, double cy, const int prec[4], const float* d_zbuf, int Himg, int Wimg, double eps, int eps_f32,
+                          uint8_t* d_mask);
+
 /* ---- compute_partwise_iou, reference utils/camera_estimation.py:770-787 -------------------
  * per colour k: inter[k] = #(a==c & b==c), uni[k] = #(a==c | b==c) over npix RGB pixels. */
 int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64_t npix,

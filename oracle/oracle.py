@@ -455,3 +455,58 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
         grid = recolor_backward_components(oriented, part_colors_np["front_minarets"], new_color=part_colors_np["back_minarets"],
                                            k=2, sort_axis=0)
     return grid
+
+
+# ---- N4: camera objective; N5: z-buffer visibility --------------------------------------------------------
+def mask_parts_from_image(image, part_colors, selected_parts):
+    """mask_utils.py:89-97: the image with everything but the selected parts' colours blacked out."""
+    img = np.asarray(image)
+    out = np.zeros_like(img)
+    for part in selected_parts:
+        c = np.asarray(part_colors[part])
+        hit = (img[..., 0] == c[0]) & (img[..., 1] == c[1]) & (img[..., 2] == c[2])
+        out[hit] = c
+    return out
+
+
+def camera_objective(voxel_pts, voxel_colors, seg_img, selected_labels, p, H, W):
+    """evaluate() of launch_smart_aligner, camera_estimation.py:597-603: minus the mean part IoU."""
+    proj = project_colored_voxels(voxel_pts, voxel_colors, p["cam_pos"], p["target"], p["f"], p["cx"], p["cy"], H, W)
+    _, iou = compute_partwise_iou(proj, seg_img, selected_labels)
+    return -iou
+
+
+def _pin_args(pts3d, cam):
+    pts3d = np.asarray(pts3d)
+    cam_pos = np.asarray(cam["cam_pos"]); target = np.asarray(cam["target"])
+    R = look_at_rotation(cam_pos, target)
+    t0 = int(np.result_type(pts3d, cam_pos, R) == np.float64)
+    tm = int(t0 or _is_f64_scalar(cam["f"]))
+    tu = int(tm or _is_f64_scalar(cam["cx"])); tv = int(tm or _is_f64_scalar(cam["cy"]))
+    prec = (C.c_int * 4)(t0, tm, tu, tv)
+    pf64 = int(pts3d.dtype == np.float64)
+    p = np.ascontiguousarray(pts3d, np.float64 if pf64 else np.float32)
+    return p, pf64, np.ascontiguousarray(R, np.float64), np.ascontiguousarray(cam_pos, np.float64), prec, t0
+
+
+def compute_global_depth_buffer(voxel_grid, cam, H, W):
+    """eval_helpers_intra.py:134-163."""
+    pts, _, _ = voxel_grid_to_points(voxel_grid, stride=1)
+    p, pf64, R, cp, prec, _ = _pin_args(pts, cam)
+    zbuf = np.empty((H, W), np.float32)
+    lib().orc_depth_buffer(p.ctypes.data_as(C.c_void_p), pf64, _i64(len(p)), _dp(R), _dp(cp), C.c_double(float(cam["f"])),
+                           C.c_double(float(cam["cx"])), C.c_double(float(cam["cy"])), prec, int(H), int(W),
+                           zbuf.ctypes.data_as(C.POINTER(C.c_float)))
+    return zbuf
+
+
+def project_part_visible(pts3d, cam, zbuf, H, W, eps=1e-3):
+    """eval_helpers_intra.py:168-190."""
+    p, pf64, R, cp, prec, t0 = _pin_args(pts3d, cam)
+    zb = np.ascontiguousarray(zbuf, np.float32)
+    mask = np.zeros((H, W), np.uint8)
+    eps_f32 = int((not t0) and not _is_f64_scalar(eps))
+    lib().orc_visible_mask(p.ctypes.data_as(C.c_void_p), pf64, _i64(len(p)), _dp(R), _dp(cp), C.c_double(float(cam["f"])),
+                           C.c_double(float(cam["cx"])), C.c_double(float(cam["cy"])), prec, zb.ctypes.data_as(C.POINTER(C.c_float)),
+                           int(H), int(W), C.c_double(float(eps)), eps_f32, _p(mask))
+    return mask.astype(bool)

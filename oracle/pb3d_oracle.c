@@ -475,3 +475,62 @@ i64 orc_label6(const u8* mask, i64 A0, i64 A1, i64 A2, int32_t* labels) {
     free(p);
     return next;
 }
+
+/* ------------------------------------------------------------------------------------
+ * N5: z-buffer visibility -- reference utils/eval_helpers_intra.py:134-163 (compute_global_depth_buffer)
+ * and :168-190 (project_part_visible).  Same pinhole arithmetic as orc_project, except that points
+ * with Z <= 1e-6 are dropped instead of clamped.  Sequential loops exactly as upstream.
+ * ---------------------------------------------------------------------------------- */
+static int orc_pin(const void* pts, int pts_f64, i64 i, const double R[9], const double cam[3], double f, double cx, double cy,
+                   const int prec[4], int Himg, int Wimg, i64* ui, i64* vi, double* zout) {
+    const int t0 = prec[0], tm = prec[1], tu = prec[2], tv = prec[3];
+    double p[3];
+    for (int k = 0; k < 3; ++k)
+        p[k] = pts_f64 ? ((const double*)pts)[3 * i + k] : (double)((const float*)pts)[3 * i + k];
+    double pc[3];
+    if (t0) {
+        double d[3];
+        for (int k = 0; k < 3; ++k) d[k] = p[k] - cam[k];
+        for (int r = 0; r < 3; ++r) pc[r] = fma(d[2], R[3 * r + 2], fma(d[1], R[3 * r + 1], d[0] * R[3 * r + 0]));
+    } else {
+        float df[3];
+        for (int k = 0; k < 3; ++k) df[k] = (float)p[k] - (float)cam[k];
+        for (int r = 0; r < 3; ++r)
+            pc[r] = (double)fmaf(df[2], (float)R[3 * r + 2], fmaf(df[1], (float)R[3 * r + 1], df[0] * (float)R[3 * r + 0]));
+    }
+    const double X = pc[0], Y = pc[1], Z = pc[2];
+    if (!(Z > (t0 ? 1e-6 : (double)(float)1e-6))) return 0;
+    double qx = orc_rnd(X / Z, t0), qy = -orc_rnd(Y / Z, t0);
+    double fm = tm ? f : (double)(float)f;
+    double mu = orc_rnd(qx * fm, tm), mv = orc_rnd(qy * fm, tm);
+    double u = orc_rnd(mu + (tu ? cx : (double)(float)cx), tu);
+    double v = orc_rnd(mv + (tv ? cy : (double)(float)cy), tv);
+    double ur = nearbyint(u), vr = nearbyint(v);
+    if (!(ur >= 0 && ur < (double)Wimg && vr >= 0 && vr < (double)Himg)) return 0;
+    *ui = (i64)ur; *vi = (i64)vr; *zout = Z;
+    return 1;
+}
+
+void orc_depth_buffer(const void* pts, int pts_f64, i64 n, const double R[9], const double cam[3], double f, double cx, double cy,
+                      const int prec[4], int Himg, int Wimg, float* zbuf) {
+    for (i64 k = 0; k < (i64)Himg * Wimg; ++k) zbuf[k] = INFINITY;
+    for (i64 i = 0; i < n; ++i) {
+        i64 ui, vi; double z;
+        if (!orc_pin(pts, pts_f64, i, R, cam, f, cx, cy, prec, Himg, Wimg, &ui, &vi, &z)) continue;
+        if (z < (double)zbuf[vi * Wimg + ui]) zbuf[vi * Wimg + ui] = (float)z;
+    }
+}
+
+void orc_visible_mask(const void* pts, int pts_f64, i64 n, const double R[9], const double cam[3], double f, double cx, double cy,
+                      const int prec[4], const float* zbuf, int Himg, int Wimg, double eps, int eps_f32, u8* mask) {
+    memset(mask, 0, (size_t)Himg * Wimg);
+    for (i64 i = 0; i < n; ++i) {
+        i64 ui, vi; double z;
+        if (!orc_pin(pts, pts_f64, i, R, cam, f, cx, cy, prec, Himg, Wimg, &ui, &vi, &z)) continue;
+        const float zb = zbuf[vi * Wimg + ui];
+        int hit;
+        if (prec[0]) hit = fabs(z - (double)zb) < eps;
+        else { const float dz = fabsf((float)z - zb); hit = eps_f32 ? dz < (float)eps : (double)dz < eps; }
+        if (hit) mask[vi * Wimg + ui] = 1;
+    }
+}

@@ -21,7 +21,11 @@ struct ProjParams {
 
 __device__ __forceinline__ double rnd(double v, int is64) { return is64 ? v : (double)(float)v; }
 
-__device__ __forceinline__ bool project_point(const ProjParams& P, const void* __restrict__ pts, i64 i, int* ui, int* vi) {
+// mode 0: project_colored_voxels (Z < 1e-8 clamped to 1e-8); mode 1: the z-buffer functions of
+// reference utils/eval_helpers_intra.py:134-190 (points with Z <= 1e-6 are dropped, no clamp)
+template <int MODE>
+__device__ __forceinline__ bool project_point(const ProjParams& P, const void* __restrict__ pts, i64 i, int* ui, int* vi,
+                                              double* zout = nullptr) {
     double p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -42,8 +46,14 @@ __device__ __forceinline__ bool project_point(const ProjParams& P, const void* _
     }
     const double X = pc[0], Y = pc[1];
     double Z = pc[2];
-    const double zmin = P.t0 ? 1e-8 : (double)(float)1e-8;
-    if (Z < zmin) Z = zmin;
+    if (MODE == 0) {
+        const double zmin = P.t0 ? 1e-8 : (double)(float)1e-8;
+        if (Z < zmin) Z = zmin;
+    } else {
+        const double zthr = P.t0 ? 1e-6 : (double)(float)1e-6;
+        if (!(Z > zthr)) return false;
+        if (zout) *zout = Z;
+    }
     const double qx = rnd(__ddiv_rn(X, Z), P.t0);
     const double qy = -rnd(__ddiv_rn(Y, Z), P.t0);
     const double fm = P.tm ? P.f : (double)(float)P.f;
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256) void k_project_points(const void* __restrict__
     for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
         const i64 i = n - 1 - t;
         int ui, vi;
-        if (project_point(P, pts, i, &ui, &vi)) {
+        if (project_point<0>(P, pts, i, &ui, &vi)) {
             u32* w = &winner[(i64)vi * P.Wimg + ui];
             const u32 mine = (u32)(i + 1);
             if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(w, mine);
@@ -81,6 +91,33 @@ __global__ __launch_bounds__(256) void k_project_resolve(const u32* __restrict__
             r = c[0]; g = c[1]; b = c[2];
         }
         img[3 * px] = r; img[3 * px + 1] = g; img[3 * px + 2] = b;
+    }
+}
+
+// z-buffer: nearest depth per pixel.  Depths are positive, so float32 order == order of their bit patterns and
+// the sequential "if z < zbuf: zbuf = z" loop of the reference equals an atomicMin on the float32 bits of z
+// (for float64 cameras the stored value is float32(z); float32 rounding is monotone, so min and rounding commute).
+__global__ __launch_bounds__(256) void k_depth_points(const void* __restrict__ pts, i64 n, ProjParams P, u32* __restrict__ zbits) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        int ui, vi; double z;
+        if (project_point<1>(P, pts, i, &ui, &vi, &z)) atomicMin(&zbits[(i64)vi * P.Wimg + ui], __float_as_uint((float)z));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_visible_points(const void* __restrict__ pts, i64 n, ProjParams P, const float* __restrict__ zbuf,
+                                                        double eps, int eps_f32, u8* __restrict__ mask) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        int ui, vi; double z;
+        if (!project_point<1>(P, pts, i, &ui, &vi, &z)) continue;
+        const i64 px = (i64)vi * P.Wimg + ui;
+        const float zb = zbuf[px];
+        bool hit;
+        if (P.t0) hit = fabs(__dsub_rn(z, (double)zb)) < eps;                       // float64 z - float32 zbuf -> float64
+        else {
+            const float dz = fabsf(__fsub_rn((float)z, zb));                         // float32 z - float32 zbuf
+            hit = eps_f32 ? dz < (float)eps : (double)dz < eps;                     // weak Python float -> float32 compare
+        }
+        if (hit) mask[px] = 1;
     }
 }
 
@@ -151,6 +188,51 @@ int pb3d_project_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_
     hipLaunchKernelGGL(k_project_resolve, dim3(pb3d_stream_blocks(ctx, npix, 256, 8)), dim3(256), 0, ctx->stream,
                        (const u32*)winner, d_cols, d_img, npix);
     PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+static int fill_proj(ProjParams* P, int pts_f64, const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4],
+                     int Himg, int Wimg) {
+    for (int k = 0; k < 4; ++k) PB3D_REQUIRE(prec[k] == 0 || prec[k] == 1, "pb3d projection: prec[%d] must be 0 or 1", k);
+    PB3D_REQUIRE(prec[1] >= prec[0] && prec[2] >= prec[1] && prec[3] >= prec[1], "pb3d projection: precision may only widen");
+    memcpy(P->R, R, sizeof(P->R)); memcpy(P->cam, cam, sizeof(P->cam));
+    P->f = f; P->cx = cx; P->cy = cy;
+    P->t0 = prec[0]; P->tm = prec[1]; P->tu = prec[2]; P->tv = prec[3];
+    P->Himg = Himg; P->Wimg = Wimg; P->pts_f64 = pts_f64 ? 1 : 0;
+    return PB3D_OK;
+}
+
+int pb3d_depth_buffer_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, int64_t n, const double R[9], const double cam[3], double f,
+                          double cx, double cy, const int prec[4], int Himg, int Wimg, float* d_zbuf) {
+    PB3D_REQUIRE(ctx && R && cam && prec && n >= 0 && Himg >= 0 && Wimg >= 0, "pb3d_depth_buffer: bad argument");
+    const i64 npix = (i64)Himg * Wimg;
+    if (npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_zbuf && (n == 0 || d_pts), "pb3d_depth_buffer: null buffer");
+    ProjParams P;
+    PB3D_TRY(fill_proj(&P, pts_f64, R, cam, f, cx, cy, prec, Himg, Wimg));
+    PB3D_HIP(hipMemsetD32Async((hipDeviceptr_t)d_zbuf, 0x7f800000, (size_t)npix, ctx->stream));   // +inf
+    if (n > 0) {
+        hipLaunchKernelGGL(k_depth_points, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_pts, n, P, (u32*)d_zbuf);
+        PB3D_CHECK_LAUNCH();
+    }
+    return PB3D_OK;
+}
+
+int pb3d_visible_mask_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, int64_t n, const double R[9], const double cam[3], double f,
+                          double cx, double cy, const int prec[4], const float* d_zbuf, int Himg, int Wimg, double eps, int eps_f32,
+                          uint8_t* d_mask) {
+    PB3D_REQUIRE(ctx && R && cam && prec && n >= 0 && Himg >= 0 && Wimg >= 0, "pb3d_visible_mask: bad argument");
+    const i64 npix = (i64)Himg * Wimg;
+    if (npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_zbuf && d_mask && (n == 0 || d_pts), "pb3d_visible_mask: null buffer");
+    ProjParams P;
+    PB3D_TRY(fill_proj(&P, pts_f64, R, cam, f, cx, cy, prec, Himg, Wimg));
+    PB3D_HIP(hipMemsetAsync(d_mask, 0, (size_t)npix, ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_visible_points, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_pts, n, P, d_zbuf, eps,
+                           eps_f32, d_mask);
+        PB3D_CHECK_LAUNCH();
+    }
     return PB3D_OK;
 }
 

@@ -6,7 +6,9 @@ utils.config) on top of libpb3d.so.  `install()` rebinds those names inside an i
 reference `utils` package so notebooks 1-3 run unchanged.
 """
 from . import _lib, device, dist  # noqa: F401
-from .camera_estimation import compute_partwise_iou  # noqa: F401
+from .camera_estimation import CameraObjective, compute_partwise_iou  # noqa: F401
+from .eval_helpers_intra import compute_global_depth_buffer, project_part_visible  # noqa: F401
+from .mask_utils import mask_parts_from_image  # noqa: F401
 from .camera_geometry import look_at_rotation, project  # noqa: F401
 from .deformation_estimation import build_deformed_grid, deform_coords, deform_part, evaluate_part_deform  # noqa: F401
 from .config import INTERIOR_PARTS, MAX_DIM, PART_COLORS, PART_COLORS_NP  # noqa: F401
@@ -23,6 +25,7 @@ _PATCH = {
     "voxel_utils": ["get_voxel_points_by_parts", "voxel_grid_to_points"],
     "projection_utils": ["project_colored_voxels"],
     "camera_estimation": ["compute_partwise_iou"],
+    "eval_helpers_intra": ["compute_global_depth_buffer", "project_part_visible"],
 }
 
 

@@ -61,6 +61,9 @@ _SIGNATURES = {
     "pb3d_project_dev": [vp, vp, C.c_int, vp, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],
     "pb3d_project": [vp, vp, C.c_int, u8p, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, u8p],
     "pb3d_partwise_iou_dev": [vp, vp, vp, i64, u8p, C.c_int, i64p, i64p],
+    "pb3d_depth_buffer_dev": [vp, vp, C.c_int, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],
+    "pb3d_visible_mask_dev": [vp, vp, C.c_int, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, vp, C.c_int, C.c_int,
+                              C.c_double, C.c_int, vp],
     "pb3d_partwise_iou": [vp, u8p, u8p, i64, u8p, C.c_int, i64p, i64p],
     "pb3d_deform_count_dev": [vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64p],
     "pb3d_deform_fill_dev": [vp, i64, vp],

@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["compute_partwise_iou"]
+__all__ = ["compute_partwise_iou", "CameraObjective"]
 
 
 def partwise_iou_counts(proj_mask, gt_mask, colors):
@@ -37,3 +37,68 @@ def compute_partwise_iou(proj_mask, gt_mask, part_colors):
     for name, i, u in zip(names, inter, uni):
         per_part[name] = (i / u) if u > 0 else 0.0
     return per_part, np.mean(list(per_part.values()))
+
+
+class CameraObjective:
+    """The objective of the camera aligner, reference utils/camera_estimation.py:597-603
+    (`evaluate(p)` = minus the mean IoU of the selected parts between the projection and the part image),
+    with the point cloud, its colours and the image RESIDENT in HBM: the random / coordinate / Powell loops
+    (:606-725) re-project the same points hundreds of times and only the nine camera numbers change.
+
+        obj = CameraObjective(voxel_pts, voxel_colors, seg_img, selected_labels)
+        value = obj(p)                       # p: dict with cam_pos, target, f, cx, cy (H, W default to the image's)
+        values = obj.evaluate_batch([p1, p2, ...])
+    """
+
+    def __init__(self, voxel_pts, voxel_colors, seg_img, selected_labels):
+        from . import device as dev
+        self._dev = dev
+        pts = np.asarray(voxel_pts)
+        self._pf64 = int(pts.dtype == np.float64)
+        self._pts_dtype = pts.dtype
+        self._pts_host = np.ascontiguousarray(pts, np.float64 if self._pf64 else np.float32)
+        if self._pts_host.ndim != 2 or self._pts_host.shape[1] != 3:
+            raise ValueError("voxel_pts must be (N,3)")
+        cols = np.ascontiguousarray(np.asarray(voxel_colors).astype(np.uint8, copy=False))
+        if cols.shape != (len(self._pts_host), 3):
+            raise ValueError("voxel_colors must be (N,3)")
+        self.n = len(self._pts_host)
+        seg = _lib.as_u8(seg_img, "seg_img")
+        self.H, self.W = seg.shape[:2]
+        self.names = list(selected_labels.keys())
+        self._colors = np.ascontiguousarray(np.array([selected_labels[k] for k in self.names], np.uint8).reshape(-1, 3))
+        if len(self._colors) > 32:
+            raise ValueError("at most 32 parts")
+        self._d_pts = dev.from_numpy(self._pts_host) if self.n else None
+        self._d_cols = dev.from_numpy(cols) if self.n else None
+        self._d_seg = dev.from_numpy(seg)
+        self._d_img = dev.DeviceBuffer(self.H * self.W * 3)
+
+    def __call__(self, p):
+        from .projection_utils import camera_args
+        H, W = int(p.get("H", self.H)), int(p.get("W", self.W))
+        if (H, W) != (self.H, self.W):
+            raise ValueError("operands could not be broadcast together: projection and part image differ in size")
+        # only dtypes matter for the promotion flags: a one-row stand-in avoids touching the resident points
+        _, _, R, cam, prec = camera_args(np.zeros((1, 3), self._pts_dtype), p["cam_pos"], p["target"], p["f"], p["cx"], p["cy"])
+        lib, ctx = _lib.load(), _lib.ctx()
+        _lib.check(lib.pb3d_project_dev(ctx, None if not self.n else C.c_void_p(self._d_pts.ptr), self._pf64,
+                                        None if not self.n else C.c_void_p(self._d_cols.ptr), self.n, _lib.p_dbl(R), _lib.p_dbl(cam),
+                                        float(p["f"]), float(p["cx"]), float(p["cy"]), prec, H, W, C.c_void_p(self._d_img.ptr)))
+        inter = np.zeros(len(self._colors), np.int64); uni = np.zeros(len(self._colors), np.int64)
+        _lib.check(lib.pb3d_partwise_iou_dev(ctx, C.c_void_p(self._d_img.ptr), C.c_void_p(self._d_seg.ptr), H * W, _lib.p_u8(self._colors),
+                                             len(self._colors), inter.ctypes.data_as(_lib.i64p), uni.ctypes.data_as(_lib.i64p)))
+        per = [(i / u) if u > 0 else 0.0 for i, u in zip(inter, uni)]
+        return -np.mean(per)
+
+    def evaluate_batch(self, params):
+        return [self(p) for p in params]
+
+    def projection(self):
+        """the image of the last evaluation (H,W,3)"""
+        return self._d_img.download((self.H, self.W, 3))
+
+    def close(self):
+        for b in (self._d_pts, self._d_cols, self._d_seg, self._d_img):
+            if b is not None:
+                b.free()

@@ -16,6 +16,21 @@ def _promotes_to_f64(v):
     return False
 
 
+def camera_args(pts3d, cam_pos, target, f, cx, cy):
+    """Everything the projection kernels need from the caller's camera: the look-at rotation (host NumPy, same
+    dtypes as upstream), the points in their own float width and the NumPy-2 promotion flags of each stage."""
+    pts3d = np.asarray(pts3d)
+    cam_pos = np.asarray(cam_pos)
+    target = np.asarray(target)
+    R = look_at_rotation(cam_pos, target)
+    t0 = int(np.result_type(pts3d, cam_pos, R) == np.float64)
+    tm = int(t0 or _promotes_to_f64(f))
+    prec = (C.c_int * 4)(t0, tm, int(tm or _promotes_to_f64(cx)), int(tm or _promotes_to_f64(cy)))
+    pf64 = int(pts3d.dtype == np.float64)
+    return (np.ascontiguousarray(pts3d, np.float64 if pf64 else np.float32), pf64, np.ascontiguousarray(R, np.float64),
+            np.ascontiguousarray(cam_pos, np.float64), prec)
+
+
 def project_colored_voxels(pts3d, colors, cam_pos, target, f, cx, cy, H, W):
     """(H,W,3) uint8 image of the points seen from cam_pos looking at target; among points that
     land on one pixel the last in input order wins (NumPy fancy-assignment semantics)."""

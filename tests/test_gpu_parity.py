@@ -440,3 +440,35 @@ def test_rccl_allgather_single_rank(pb3d_gpu):
         assert np.array_equal(d_dst.download(slab.shape), slab)
     finally:
         dist.comm_destroy()
+
+
+@pytest.mark.parametrize("mon", ["Akbar", "Charminar"])
+def test_camera_objective_and_zbuffer_n45(pb3d_gpu, mon):
+    """rows N4 / N5: the resident camera objective over perturbed cameras (float64 parameters, as the aligner's
+    sliders / optimisers produce them) and the z-buffer visibility functions, against the reference's values."""
+    g = np.load(os.path.join(GOLDEN, "n45_objective_zbuffer.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "n45_objective_zbuffer.json")))
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = pb3d_gpu.PART_COLORS
+    m = meta[f"objective_{mon}"]
+    front = np.load(os.path.join(GOLDEN, "f7_projection.npz"))[f"img_{mon}_front"]
+    seg = pb3d_gpu.mask_parts_from_image(front, PC, m["parts"])
+    assert np.array_equal(seg, g[f"seg_{mon}"])
+    pts, cols = pb3d_gpu.get_voxel_points_by_parts(grid, PC, m["parts"])
+    obj = pb3d_gpu.CameraObjective(pts, cols, seg, {p: PC[p] for p in m["parts"]})
+    params = [{"cam_pos": np.array(t["cam_pos"]), "target": np.array(t["target"]), "f": t["f"], "cx": t["cx"], "cy": t["cy"],
+               "H": m["H"], "W": m["W"]} for t in m["trials"]]
+    got = obj.evaluate_batch(params)
+    assert got == [t["neg_iou"] for t in m["trials"]]
+    assert obj(params[0]) == m["trials"][0]["neg_iou"]          # re-evaluation on the resident cloud is stable
+    obj.close()
+    cams = _cams(mon)["front"]
+    for mode in ("f32", "f64"):
+        if f"zbuf_{mon}_{mode}" not in g.files:
+            continue
+        cam = {k: (v.astype(np.float64) if (mode == "f64" and isinstance(v, np.ndarray)) else v) for k, v in cams.items()}
+        zbuf = pb3d_gpu.compute_global_depth_buffer(grid, cam, m["H"], m["W"])
+        assert zbuf.dtype == np.float32 and np.array_equal(zbuf, g[f"zbuf_{mon}_{mode}"])
+        ppts, _ = pb3d_gpu.get_voxel_points_by_parts(grid, PC, ["front_minarets"])
+        vis = pb3d_gpu.project_part_visible(ppts, cam, zbuf, m["H"], m["W"])
+        assert vis.dtype == bool and np.array_equal(vis, g[f"vis_{mon}_{mode}"])

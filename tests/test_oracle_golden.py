@@ -258,3 +258,36 @@ def test_partwise_stages_f5(oracle, golden, name, capsys):
     assert sha(full) == meta["partwise_sha256"] and list(full.shape) == meta["partwise_shape"]
     assert np.array_equal(oracle.extrude_from_surface(pc, np.all(g["sem"] == PCN["full_building"], axis=-1), 2, "-", 3, None), g["extrude_none"])
     assert np.array_equal(oracle.recolor_backward_components(pc, PCN["front_minarets"], PCN["windows"], k=1, sort_axis=2), g["recolor_k1_axis2"])
+
+
+def _n45():
+    return (np.load(os.path.join(GOLDEN, "n45_objective_zbuffer.npz")), json.load(open(os.path.join(GOLDEN, "n45_objective_zbuffer.json"))))
+
+
+@pytest.mark.parametrize("mon", ["Akbar", "Charminar"])
+def test_camera_objective_and_zbuffer_n45(oracle, mon):
+    """rows N4 / N5 against the reference: objective of the camera aligner over perturbed cameras; whole-object depth
+    buffer and visibility mask of one part."""
+    g, meta = _n45()
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = oracle.PART_COLORS
+    m = meta[f"objective_{mon}"]
+    front = np.load(os.path.join(GOLDEN, "f7_projection.npz"))[f"img_{mon}_front"]
+    seg = oracle.mask_parts_from_image(front, PC, m["parts"])
+    assert np.array_equal(seg, g[f"seg_{mon}"])
+    pts, cols = oracle.get_voxel_points_by_parts(grid, PC, m["parts"])
+    assert len(pts) == m["npts"]
+    sel = {p: PC[p] for p in m["parts"]}
+    for t in m["trials"]:
+        p = {"cam_pos": np.array(t["cam_pos"]), "target": np.array(t["target"]), "f": t["f"], "cx": t["cx"], "cy": t["cy"]}
+        assert oracle.camera_objective(pts, cols, seg, sel, p, m["H"], m["W"]) == t["neg_iou"]
+    cams = _cams(mon)["front"]
+    for mode in ("f32", "f64"):
+        if f"zbuf_{mon}_{mode}" not in g.files:
+            continue
+        cam = {k: (v.astype(np.float64) if (mode == "f64" and isinstance(v, np.ndarray)) else v) for k, v in cams.items()}
+        zbuf = oracle.compute_global_depth_buffer(grid, cam, m["H"], m["W"])
+        assert zbuf.dtype == np.float32 and np.array_equal(zbuf, g[f"zbuf_{mon}_{mode}"])
+        ppts, _ = oracle.get_voxel_points_by_parts(grid, PC, ["front_minarets"])
+        vis = oracle.project_part_visible(ppts, cam, zbuf, m["H"], m["W"])
+        assert vis.dtype == bool and np.array_equal(vis, g[f"vis_{mon}_{mode}"])
