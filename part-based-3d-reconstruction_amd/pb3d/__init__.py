@@ -8,7 +8,7 @@ reference `utils` package so notebooks 1-3 run unchanged.
 from . import _lib, device, dist  # noqa: F401
 from .camera_estimation import CameraObjective, compute_partwise_iou  # noqa: F401
 from .eval_helpers_intra import compute_global_depth_buffer, project_part_visible  # noqa: F401
-from .mask_utils import mask_parts_from_image  # noqa: F401
+from .mask_utils import load_and_prepare_masks, load_mask, mask_parts_from_image  # noqa: F401
 from .camera_geometry import look_at_rotation, project  # noqa: F401
 from .deformation_estimation import build_deformed_grid, deform_coords, deform_part, evaluate_part_deform  # noqa: F401
 from .config import INTERIOR_PARTS, MAX_DIM, PART_COLORS, PART_COLORS_NP  # noqa: F401

@@ -1,4 +1,6 @@
 """CPU-only: host-side logic of the shim that mirrors reference behaviour without touching the GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,3 +94,27 @@ def test_install_patches_a_utils_like_package():
         assert sub.process_voxel_grid is pb3d.process_voxel_grid and sub.launch_smart_aligner() == "kept"
     finally:
         del sys.modules["fakeutils"], sys.modules["fakeutils.voxel_carving_utils"]
+
+
+def test_mask_ingest_n3(golden, tmp_path):
+    """row N3: PNG -> (semantic, exterior, binary) at max_dim without OpenCV.  The Taj masks at 512 are the ones with
+    which the carve path reproduces the reference's stored results/1 grid position-exactly (test_results1_*), and the
+    resized shape (139, 256) is the one notebook 1 prints for Taj at max_dim = 256."""
+    import shutil
+    from conftest import GOLDEN
+    import pb3d
+    for mon in ("Taj", "Akbar"):
+        d = tmp_path / "data" / mon / "masks"; d.mkdir(parents=True)
+        shutil.copyfile(os.path.join(GOLDEN, f"data_{mon}_front_mask.png"), d / f"{mon}_front_mask.png")
+    root = str(tmp_path / "data")
+    for mon, dim, fx in (("Taj", 512, "f9_Taj_512_masks"), ("Taj", 256, "f4_Taj_256_masks"), ("Akbar", 128, "f4_Akbar_128_masks")):
+        sem, ext, binary = pb3d.load_and_prepare_masks(root, mon, "front", dim, pb3d.PART_COLORS_NP, pb3d.INTERIOR_PARTS)
+        g = golden(fx)
+        assert np.array_equal(sem, g["sem"]) and np.array_equal(ext, g["ext"]) and np.array_equal(binary, g["binary"])
+        assert binary.dtype == np.uint8 and sem.dtype == np.uint8
+    assert pb3d.load_and_prepare_masks(root, "Taj", "front", 256, pb3d.PART_COLORS_NP, pb3d.INTERIOR_PARTS)[0].shape == (139, 256, 3)
+    full = pb3d.load_mask(root, "Taj", "front")
+    assert full.shape == (660, 1214, 3)
+    assert np.array_equal(pb3d.load_mask(root, "Taj", "front", 512), golden("f9_Taj_512_masks")["sem"])
+    with pytest.raises(FileNotFoundError):
+        pb3d.load_mask(root, "Bibi", "front")
