@@ -214,6 +214,9 @@ int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t 
                                 const uint8_t new_color[3], uint8_t* d_grid_rgb);
 int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
                      int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out);
+/* notebook-1 output orientation, reference utils/voxel_carving_utils.py:384-385:
+ * out (D,H,W,3) = flip(grid.transpose(2,1,0,3), axis=1) of the (W,H,D,3) grid, C-contiguous. */
+int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, uint8_t* d_out);
 
 /* ---- seeded synthetic inputs generated on the device ---------------------
  * mask16: labels (S,S) uint8 in 0..15 by the closed formula scaled from S=1024; binary and

@@ -229,6 +229,26 @@ __global__ __launch_bounds__(256) void k_extrude_x(const u8* __restrict__ src, u
     }
 }
 
+// notebook-1 output orientation (reference :384-385): oriented = flip(grid.transpose(2,1,0,3), axis=1), i.e.
+// out[z, b, x, :] = grid[x, H-1-b, z, :] as a C-contiguous (D,H,W,3) array.  32x32 (x,z) tiles through LDS.
+__global__ __launch_bounds__(256) void k_orient(const u8* __restrict__ grid, u8* __restrict__ out, i64 W, i64 H, i64 D) {
+    __shared__ u8 t[32][32 * 3 + 4];
+    const i64 x0 = (i64)blockIdx.x * 32, z0 = (i64)blockIdx.y * 32, y = blockIdx.z;
+    for (int i = threadIdx.x; i < 32 * 96; i += 256) {         // rows of the source tile: fixed x, 32 z * 3 bytes contiguous
+        const int xl = i / 96, b = i - xl * 96;
+        const i64 x = x0 + xl, zb = z0 * 3 + b;
+        t[xl][b] = (x < W && zb < D * 3) ? grid[((x * H + y) * D) * 3 + zb] : (u8)0;
+    }
+    __syncthreads();
+    const i64 yb = H - 1 - y;
+    for (int i = threadIdx.x; i < 32 * 96; i += 256) {         // rows of the destination tile: fixed z, 32 x * 3 bytes contiguous
+        const int zl = i / 96, b = i - zl * 96;
+        const int xl = b / 3, c = b - 3 * xl;
+        const i64 z = z0 + zl, x = x0 + xl;
+        if (z < D && x < W) out[((z * H + yb) * W + x) * 3 + c] = t[xl][zl * 3 + c];
+    }
+}
+
 }  // namespace
 
 int pb3d_keep_only_ones(pb3d_ctx* ctx, u8* d_img, i64 n);
@@ -357,6 +377,17 @@ int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t 
     PB3D_HIP(hipStreamSynchronize(ctx->stream));   // comp_flag is a caller-owned host buffer
     hipLaunchKernelGGL(k_recolor_flagged, dim3(pb3d_stream_blocks(ctx, nvox, 256, 8)), dim3(256), 0, ctx->stream, d_labels, (const u8*)f, nvox,
                        new_color[0], new_color[1], new_color[2], d_grid_rgb);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, uint8_t* d_out) {
+    PB3D_REQUIRE(ctx && W >= 0 && H >= 0 && D >= 0, "pb3d_orient: bad shape");
+    if (W * H * D == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid_rgb && d_out && d_grid_rgb != d_out, "pb3d_orient: null or aliased buffer");
+    PB3D_REQUIRE(H <= 65535 && (D + 31) / 32 <= 65535, "pb3d_orient: grid too large");
+    dim3 grid((unsigned)((W + 31) / 32), (unsigned)((D + 31) / 32), (unsigned)H);
+    hipLaunchKernelGGL(k_orient, grid, dim3(256), 0, ctx->stream, d_grid_rgb, d_out, W, H, D);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

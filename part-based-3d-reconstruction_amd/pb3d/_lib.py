@@ -77,6 +77,7 @@ _SIGNATURES = {
     "pb3d_component_paste_dev": [vp, vp, vp, C.c_int32, vp, i64, i64, i64, i64p, i64p, vp],
     "pb3d_recolor_components_dev": [vp, vp, i64, u8p, i64, u8p, vp],
     "pb3d_extrude_dev": [vp, vp, i64, i64, i64, vp, i64, C.c_int, C.c_int, C.c_int, u8p, vp],
+    "pb3d_orient_dev": [vp, vp, i64, i64, i64, vp],
     "pb3d_synth_mask16_dev": [vp, i64, vp, vp, vp, vp],
     "pb3d_synth_sem_dev": [vp, i64, i64, i64, i64, C.c_uint64, vp],
     "pb3d_synth_occ_dev": [vp, i64, i64, i64, i64, C.c_uint64, vp],

@@ -204,6 +204,63 @@ def _component_stats(d_labels, shape3, n):
     return bbox[:n], cnt[:n], sums[:n]
 
 
+def _check_angle_step(angle):
+    if isinstance(angle, (bool, np.bool_)) or not isinstance(angle, (int, np.integer)):
+        raise TypeError(f"'{type(angle).__name__}' object cannot be interpreted as an integer")
+    if angle == 0:
+        raise ValueError("range() arg 3 must not be zero")
+
+
+def _lrgc_dev(d_col, shape3, mask2d, target_color, angle):
+    """left_right_guided_carve on a device-resident grid; returns a new DeviceBuffer holding the carved copy."""
+    from . import device as dev
+    W, H, D = shape3
+    lib, ctx = _lib.load(), _lib.ctx()
+    nbytes = W * H * D * 3
+    d_carved = dev.DeviceBuffer(nbytes)
+    _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), nbytes))
+    d_lab = dev.DeviceBuffer(W * H * D * 4)
+    tmp = []
+    try:
+        cu8 = _color_u8(target_color)
+        num = _label(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else 0
+        print(f"[{target_color}] 3D components: {num}")
+        bbox, _, _ = _component_stats(d_lab, (W, H, D), num)
+        if num:
+            _check_angle_step(angle)
+            vmax = int(max((b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]) for b in bbox))
+            pmax = int(max((b[3] - b[0]) * (b[4] - b[1]) for b in bbox))
+            d_occ = dev.DeviceBuffer(vmax); d_out = dev.DeviceBuffer(vmax); d_tmp = dev.DeviceBuffer(vmax); d_m = dev.DeviceBuffer(pmax)
+            tmp = [d_occ, d_out, d_tmp, d_m]
+        for i in range(1, num + 1):
+            x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
+            print(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
+            Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
+            m = _lib.truth_u8(_mask_to_wh(mask2d[y0:y1, x0:x1], Wc, Hc))
+            d_m.upload(m)
+            lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
+            _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
+            if angle < 0:
+                src = d_occ     # empty angle loop: the crop's occupancy is returned as is
+            else:
+                dev.process_grid(d_occ, Wc, Hc, Dc, d_m, int(min(angle, 91)), d_out, d_tmp)
+                src = d_out
+            cnt = C.c_int64(0)
+            _lib.check(lib.pb3d_points_count_dev(ctx, C.c_void_p(src.ptr), Wc, Hc, Dc, 1, None, 0, 1, C.byref(cnt)))
+            print(f"    carved voxels: {cnt.value}")
+            _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
+                                                    lo, hi, C.c_void_p(d_carved.ptr)))
+        dev.sync()
+        return d_carved
+    except BaseException:
+        d_carved.free()
+        raise
+    finally:
+        d_lab.free()
+        for b in tmp:
+            b.free()
+
+
 def left_right_guided_carve(colored_grid, semantic_mask, target_color, angle=60, visualize=False, stride=2):
     """Per 3-D connected component of `target_color`: crop its bounding box, rotate-and-carve the crop's
     occupancy with the part's own angle step against the cropped 2-D mask, clear the component and paste
@@ -217,50 +274,45 @@ def left_right_guided_carve(colored_grid, semantic_mask, target_color, angle=60,
     if not np.any(mask2d):
         print(f"[SKIP] No mask for color {target_color}")
         return g.copy()
-    lib, ctx = _lib.load(), _lib.ctx()
     d_col = dev.from_numpy(g)
-    d_carved = dev.DeviceBuffer(g.size)
-    _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), g.size))
-    d_lab = dev.DeviceBuffer(W * H * D * 4)
-    bufs = [d_col, d_carved, d_lab]
     try:
-        cu8 = _color_u8(target_color)
-        num = _label(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else 0
-        print(f"[{target_color}] 3D components: {num}")
-        bbox, _, _ = _component_stats(d_lab, (W, H, D), num)
-        for i in range(1, num + 1):
-            x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
-            print(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
-            Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
-            crop2d = mask2d[y0:y1, x0:x1]
-            m = _lib.truth_u8(_mask_to_wh(crop2d, Wc, Hc))
-            lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
-            nv = Wc * Hc * Dc
-            d_occ = dev.DeviceBuffer(nv); d_out = dev.DeviceBuffer(nv); d_tmp = dev.DeviceBuffer(nv); d_m = dev.from_numpy(m)
-            try:
-                _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
-                if isinstance(angle, (bool, np.bool_)) or not isinstance(angle, (int, np.integer)):
-                    raise TypeError(f"'{type(angle).__name__}' object cannot be interpreted as an integer")
-                if angle == 0:
-                    raise ValueError("range() arg 3 must not be zero")
-                if angle < 0:
-                    src = d_occ   # empty angle loop: the crop's occupancy is returned as is
-                else:
-                    dev.process_grid(d_occ, Wc, Hc, Dc, d_m, int(min(angle, 91)), d_out, d_tmp)
-                    src = d_out
-                cnt = C.c_int64(0)
-                _lib.check(lib.pb3d_points_count_dev(ctx, C.c_void_p(src.ptr), Wc, Hc, Dc, 1, None, 0, 1, C.byref(cnt)))
-                print(f"    carved voxels: {cnt.value}")
-                _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
-                                                        lo, hi, C.c_void_p(d_carved.ptr)))
-                dev.sync()
-            finally:
-                for b in (d_occ, d_out, d_tmp, d_m):
-                    b.free()
-        return d_carved.download(g.shape)
+        d_carved = _lrgc_dev(d_col, (W, H, D), mask2d, target_color, angle)
+        try:
+            return d_carved.download(g.shape)
+        finally:
+            d_carved.free()
     finally:
-        for b in bufs:
-            b.free()
+        d_col.free()
+
+
+def _extrude_args(shape3, mask_2d, axis, direction):
+    W, H, D = shape3
+    if direction not in ("+", "-"):
+        raise ValueError("direction must be '+' or '-'")
+    m = np.asarray(mask_2d)
+    if axis == 2:
+        valid, vw = m.T, H
+        if valid.shape != (W, H):
+            raise ValueError(f"operands could not be broadcast together with shapes ({W},{H}) {valid.shape}")
+    else:
+        valid, vw = m, D
+        if valid.shape != (H, D):
+            raise ValueError(f"operands could not be broadcast together with shapes ({H},{D}) {valid.shape}")
+    return _lib.truth_u8(valid), vw
+
+
+def _extrude_dev(d_in, d_out, shape3, valid_u8, vw, axis, direction, depth, fill_color):
+    from . import device as dev
+    W, H, D = shape3
+    fc = None if fill_color is None else np.ascontiguousarray(np.asarray(fill_color).astype(np.uint8).reshape(3))
+    d_v = dev.from_numpy(valid_u8)
+    try:
+        _lib.check(_lib.load().pb3d_extrude_dev(_lib.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_v.ptr), vw, int(axis),
+                                                1 if direction == "+" else 0, int(depth), None if fc is None else _lib.p_u8(fc),
+                                                C.c_void_p(d_out.ptr)))
+        dev.sync()
+    finally:
+        d_v.free()
 
 
 def extrude_from_surface(grid, mask_2d, axis, direction="+", depth=5, fill_color=None):
@@ -273,30 +325,37 @@ def extrude_from_surface(grid, mask_2d, axis, direction="+", depth=5, fill_color
     W, H, D, _ = g.shape
     if axis not in (0, 2) or int(depth) <= 0:
         return g.copy()
-    if direction not in ("+", "-"):
-        raise ValueError("direction must be '+' or '-'")
-    m = np.asarray(mask_2d)
-    if axis == 2:
-        valid = m.T
-        if valid.shape != (W, H):
-            raise ValueError(f"operands could not be broadcast together with shapes ({W},{H}) {valid.shape}")
-        vw = H
-    else:
-        valid = m
-        if valid.shape != (H, D):
-            raise ValueError(f"operands could not be broadcast together with shapes ({H},{D}) {valid.shape}")
-        vw = D
-    vt = _lib.truth_u8(valid)
-    fc = None if fill_color is None else np.ascontiguousarray(np.asarray(fill_color).astype(np.uint8).reshape(3))
-    d_in = dev.from_numpy(g); d_out = dev.DeviceBuffer(g.size); d_v = dev.from_numpy(vt)
+    vt, vw = _extrude_args((W, H, D), mask_2d, axis, direction)
+    d_in = dev.from_numpy(g); d_out = dev.DeviceBuffer(g.size)
     try:
-        _lib.check(_lib.load().pb3d_extrude_dev(_lib.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_v.ptr), vw, int(axis),
-                                                1 if direction == "+" else 0, int(depth), None if fc is None else _lib.p_u8(fc),
-                                                C.c_void_p(d_out.ptr)))
+        _extrude_dev(d_in, d_out, (W, H, D), vt, vw, axis, direction, depth, fill_color)
         return d_out.download(g.shape)
     finally:
-        for b in (d_in, d_out, d_v):
-            b.free()
+        d_in.free(); d_out.free()
+
+
+def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis):
+    """recolor_backward_components in place on a device-resident (A0,A1,A2,3) grid."""
+    from . import device as dev
+    A0, A1, A2 = shape3
+    cu8 = _color_u8(color)
+    if cu8 is None or A0 * A1 * A2 == 0:
+        return
+    d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
+    try:
+        n = _label(d_g, (A0, A1, A2), cu8, d_lab)
+        if n == 0:
+            return
+        _, cnt, sums = _component_stats(d_lab, (A0, A1, A2), n)
+        means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column
+        keep = {i for i, _ in sorted(means, key=lambda t: t[1])[:k]}
+        flags = np.array([0 if (i + 1) in keep else 1 for i in range(n)], np.uint8)
+        nc = np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
+        _lib.check(_lib.load().pb3d_recolor_components_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n,
+                                                           _lib.p_u8(nc), C.c_void_p(d_g.ptr)))
+        dev.sync()
+    finally:
+        d_lab.free()
 
 
 def recolor_backward_components(voxel_grid, color, new_color, k=4, sort_axis=2):
@@ -306,52 +365,84 @@ def recolor_backward_components(voxel_grid, color, new_color, k=4, sort_axis=2):
     g = np.ascontiguousarray(_lib.as_u8(voxel_grid, "voxel_grid"))
     if g.ndim != 4 or g.shape[3] != 3:
         raise ValueError("recolor_backward_components expects an (A0,A1,A2,3) grid")
-    A0, A1, A2, _ = g.shape
-    cu8 = _color_u8(color)
-    if cu8 is None or g.size == 0:
+    if g.size == 0:
         return g.copy()
-    d_g = dev.from_numpy(g); d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
+    d_g = dev.from_numpy(g)
     try:
-        n = _label(d_g, (A0, A1, A2), cu8, d_lab)
-        if n == 0:
-            return g.copy()
-        _, cnt, sums = _component_stats(d_lab, (A0, A1, A2), n)
-        means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column
-        keep = {i for i, _ in sorted(means, key=lambda t: t[1])[:k]}
-        flags = np.array([0 if (i + 1) in keep else 1 for i in range(n)], np.uint8)
-        nc = np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
-        _lib.check(_lib.load().pb3d_recolor_components_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n,
-                                                           _lib.p_u8(nc), C.c_void_p(d_g.ptr)))
+        _recolor_dev(d_g, g.shape[:3], color, new_color, k, sort_axis)
         return d_g.download(g.shape)
     finally:
-        d_g.free(); d_lab.free()
+        d_g.free()
 
 
 def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_full, part_colors_np, group_jobs, part_symmetry,
                    extrusion_depths, recolor_back_minarets=True, visualize=False, stride=4):
     """Part-wise refinement after global carving; reference :302-400.  Returns (D,H,W,3) when the
-    back-minaret recolouring runs (transposed + flipped, as upstream), else (W,H,D,3)."""
-    def show(grid, title):
+    back-minaret recolouring runs (transposed + flipped, as upstream), else (W,H,D,3).
+    The grid stays resident in HBM from the first stage to the last (one upload, one download); only with
+    visualize=True are intermediate grids brought back for plotting."""
+    from . import device as dev
+    g = _lib.as_u8(colored_voxel_grid, "colored_voxel_grid")
+    if g.ndim != 4 or g.shape[3] != 3:
+        raise ValueError("colored_voxel_grid must be (W,H,D,3)")
+    W, H, D, _ = g.shape
+    lib, ctx = _lib.load(), _lib.ctx()
+
+    def show(d_buf, shape, title):
         if visualize and plot_voxel is not None:
             from .voxel_utils import voxel_grid_to_points
-            pts, cols, _ = voxel_grid_to_points(grid, stride=stride)
+            pts, cols, _ = voxel_grid_to_points(d_buf.download(shape), stride=stride)
             if pts.shape[0] > 0:
                 plot_voxel(pts, cols, title=title)
 
-    grid = part_carve(colored_voxel_grid, semantic_mask_exterior, group_jobs, visualize=False)
-    show(grid, "After part-wise symmetric carving (global symmetry on each part)")
-    for part, angle in part_symmetry.items():
-        grid = left_right_guided_carve(colored_grid=grid, semantic_mask=semantic_mask_exterior, target_color=part_colors_np[part],
-                                       angle=angle, visualize=False, stride=stride)
-    show(grid, "After part-wise symmetric carving (local symmetry on each part)")
-    for part, depth in extrusion_depths.items():
-        mask = np.all(np.asarray(semantic_mask_full) == part_colors_np[part], axis=-1)
-        for axis, direction in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
-            grid = extrude_from_surface(grid, mask, axis=axis, direction=direction, depth=depth, fill_color=part_colors_np[part])
-    show(grid, "After interior extrusion")
-    if recolor_back_minarets:
-        oriented = np.flip(grid.transpose(2, 1, 0, 3), axis=1)
-        grid = recolor_backward_components(oriented, part_colors_np["front_minarets"], new_color=part_colors_np["back_minarets"],
-                                           k=2, sort_axis=0)
-        show(grid, "After back-minaret recoloring")
-    return grid
+    # 1. global symmetry per part group
+    msub, mcarve, angles, skip = _job_masks(semantic_mask_exterior, group_jobs, W, H, PART_COLORS)
+    for j in range(len(group_jobs)):
+        if not skip[j] and angles[j] <= 0:
+            raise ValueError("range() arg 3 must not be zero" if angles[j] == 0 else "negative angle steps are not supported")
+        angles[j] = min(angles[j], 91) if angles[j] > 0 else angles[j]
+    d_in = dev.from_numpy(g)
+    d_a = dev.DeviceBuffer(g.size)
+    live = [d_in, d_a]
+    try:
+        d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve)
+        live += [d_ms, d_mc]
+        _lib.check(lib.pb3d_part_carve_dev(ctx, C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr), angles, skip,
+                                           len(group_jobs), C.c_void_p(d_a.ptr)))
+        dev.sync()
+        show(d_a, g.shape, "After part-wise symmetric carving (global symmetry on each part)")
+        # 2. component-guided symmetry
+        sm_ext = np.asarray(semantic_mask_exterior)
+        for part, angle in part_symmetry.items():
+            target = part_colors_np[part]
+            mask2d = np.all(sm_ext == target, axis=-1)
+            if not np.any(mask2d):
+                print(f"[SKIP] No mask for color {target}")
+                continue
+            d_b = _lrgc_dev(d_a, (W, H, D), mask2d, target, angle)
+            live.append(d_b)
+            d_a.free(); live.remove(d_a)
+            d_a = d_b
+        show(d_a, g.shape, "After part-wise symmetric carving (local symmetry on each part)")
+        # 3. interior extrusion: four directions per part, ping-pong between two buffers
+        d_b = d_in          # the input copy is no longer needed
+        sm_full = np.asarray(semantic_mask_full)
+        for part, depth in extrusion_depths.items():
+            mask = np.all(sm_full == part_colors_np[part], axis=-1)
+            for axis, direction in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
+                if int(depth) <= 0:
+                    continue
+                vt, vw = _extrude_args((W, H, D), mask, axis, direction)
+                _extrude_dev(d_a, d_b, (W, H, D), vt, vw, axis, direction, depth, part_colors_np[part])
+                d_a, d_b = d_b, d_a
+        show(d_a, g.shape, "After interior extrusion")
+        # 4. orientation + back-minaret recolouring
+        if recolor_back_minarets:
+            _lib.check(lib.pb3d_orient_dev(ctx, C.c_void_p(d_a.ptr), W, H, D, C.c_void_p(d_b.ptr)))
+            _recolor_dev(d_b, (D, H, W), part_colors_np["front_minarets"], part_colors_np["back_minarets"], 2, 0)
+            show(d_b, (D, H, W, 3), "After back-minaret recoloring")
+            return d_b.download((D, H, W, 3))
+        return d_a.download(g.shape)
+    finally:
+        for b in live:
+            b.free()

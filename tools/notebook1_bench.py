@@ -1,0 +1,42 @@
+"""End-to-end timing of notebook 1 (global_carve + partwise_carve, notebook parameters) through the NumPy-signature
+host API -- i.e. INCLUDING H2D/D2H of every call (PCIe-inclusive; never the bench.py `value`).  Taj at max_dim 512 is the
+case the reference's stored artefact results/1 pins; its CPU timings are in BASELINE.md (23.9 s + 149.8 s)."""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "part-based-3d-reconstruction_amd"))
+import pb3d  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+group_jobs = [(["full_building"], 90), (["chhatris"], 90), (["plinth"], 90), (["front_minarets"], 90), (["small_minarets"], 90), (["dome"], 90)]
+part_symmetry = {"dome": 5, "chhatris": 45, "front_minarets": 5, "small_minarets": 5}
+extrusion_depths = {"main_door": 20, "windows": 10}
+
+g = np.load(os.path.join(GOLDEN, "f9_Taj_512_masks.npz"))
+stored = np.load(os.path.join(GOLDEN, "stored_Taj_voxel_grid.npz"))["voxel_grid"]
+PCN = pb3d.PART_COLORS_NP
+pb3d.global_carve(g["binary"][:64, :64].copy(), g["ext"][:64, :64].copy(), 90)   # context + kernels warm
+res = {}
+for rep in range(2):
+    t0 = time.perf_counter()
+    gc = pb3d.global_carve(g["binary"], g["ext"], angle_interval=90)
+    t1 = time.perf_counter()
+    pc = pb3d.part_carve(gc, g["ext"], group_jobs)
+    t2 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = pb3d.partwise_carve(gc, g["ext"], g["sem"], PCN, group_jobs, part_symmetry, extrusion_depths)
+    t3 = time.perf_counter()
+    res = {"grid": list(gc.shape), "Mvoxel": round(gc.size / 3 / 1e6, 1), "global_carve_s": round(t1 - t0, 3), "part_carve_s": round(t2 - t1, 3),
+           "partwise_carve_s": round(t3 - t2, 3), "reference_cpu_s": {"global_carve": 23.9, "part_carve": 122.7, "partwise_carve": 149.8}}
+oriented = np.flip(pc.transpose(2, 1, 0, 3), axis=1)
+eq = lambda grid, name: np.all(grid == np.array(pb3d.PART_COLORS[name], np.uint8), axis=-1)
+res["results1_pinned_parts_exact"] = bool(all(np.array_equal(eq(oriented, p), eq(stored, p)) for p in ("plinth", "chhatris")))
+res["final_shape"] = list(full.shape)
+print(json.dumps(res))
