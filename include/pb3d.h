@@ -236,6 +236,14 @@ int pb3d_comm_unique_id(uint8_t id[128]);
 int pb3d_comm_init(pb3d_ctx* ctx, const uint8_t id[128], int rank, int nranks);
 int pb3d_allgather_dev(pb3d_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int pb3d_comm_destroy(pb3d_ctx* ctx);
+/* points partition of the projection (project_colored_voxels, reference utils/projection_utils.py:5-23): a rank projects its
+ * contiguous range [index_base, index_base + n) of the point list into 64-bit keys (global index + 1) << 24 | rgb (zero = no
+ * point); pb3d_allreduce_max_u64_dev (in place, ncclMax) merges the ranks' key images; resolve writes the (H,W,3) image. */
+int pb3d_project_keys_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_t* d_cols, int64_t n, int64_t index_base,
+                          const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4], int Himg, int Wimg,
+                          uint64_t* d_keys);
+int pb3d_project_resolve_keys_dev(pb3d_ctx* ctx, const uint64_t* d_keys, int Himg, int Wimg, uint8_t* d_img);
+int pb3d_allreduce_max_u64_dev(pb3d_ctx* ctx, void* d_buf, size_t count);
 
 #ifdef __cplusplus
 }

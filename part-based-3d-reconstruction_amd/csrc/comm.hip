@@ -13,6 +13,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*);
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     const char* (*GetErrorString)(ncclResult_t);
 };
@@ -36,9 +37,10 @@ int load_rccl() {
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
     a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) {
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.AllReduce || !a.CommDestroy || !a.GetErrorString) {
         pb3d_set_error("RCCL library lacks a required symbol");
         dlclose(lib);
         return PB3D_ECOMM;
@@ -92,6 +94,15 @@ int pb3d_allgather_dev(pb3d_ctx* ctx, const void* d_send, void* d_recv, size_t b
     if (bytes_per_rank == 0) return PB3D_OK;
     PB3D_REQUIRE(d_send && d_recv, "pb3d_allgather: null buffer");
     PB3D_NCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, (ncclComm_t)ctx->rccl_comm, ctx->stream));
+    return PB3D_OK;
+}
+
+int pb3d_allreduce_max_u64_dev(pb3d_ctx* ctx, void* d_buf, size_t count) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_allreduce_max_u64: null context");
+    PB3D_REQUIRE(ctx->rccl_comm != nullptr, "pb3d_allreduce_max_u64: call pb3d_comm_init first");
+    if (count == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_buf != nullptr, "pb3d_allreduce_max_u64: null buffer");
+    PB3D_NCCL(g_rccl.AllReduce(d_buf, d_buf, count, ncclUint64, ncclMax, (ncclComm_t)ctx->rccl_comm, ctx->stream));
     return PB3D_OK;
 }
 

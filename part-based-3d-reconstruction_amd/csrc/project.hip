@@ -121,6 +121,31 @@ __global__ __launch_bounds__(256) void k_visible_points(const void* __restrict__
     }
 }
 
+// Sharded form of the scatter (points partition): every rank projects its contiguous range of the
+// point list into a private image of 64-bit keys ((global index + 1) << 24 | b << 16 | g << 8 | r); the last-writer-wins
+// rule is a max over the key, so ONE all-reduce(max) over the ranks followed by a local resolve gives every rank the
+// image the unsharded call produces, with no colour look-up across ranks.
+__global__ __launch_bounds__(256) void k_project_keys(const void* __restrict__ pts, const u8* __restrict__ cols, i64 n, i64 index_base,
+                                                      ProjParams P, unsigned long long* __restrict__ keys) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i64 i = n - 1 - t;
+        int ui, vi;
+        if (project_point<0>(P, pts, i, &ui, &vi)) {
+            unsigned long long* w = &keys[(i64)vi * P.Wimg + ui];
+            const unsigned long long mine = ((unsigned long long)(index_base + i + 1) << 24) | ((unsigned long long)cols[3 * i + 2] << 16) |
+                                            ((unsigned long long)cols[3 * i + 1] << 8) | (unsigned long long)cols[3 * i];
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(w, mine);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resolve_keys(const unsigned long long* __restrict__ keys, u8* __restrict__ img, i64 npix) {
+    for (i64 px = (i64)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (i64)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[px];
+        img[3 * px] = (u8)(k & 0xff); img[3 * px + 1] = (u8)((k >> 8) & 0xff); img[3 * px + 2] = (u8)((k >> 16) & 0xff);
+    }
+}
+
 struct IouParams {
     int ncolors;
     u8 colors[3 * 32];
@@ -199,6 +224,36 @@ static int fill_proj(ProjParams* P, int pts_f64, const double R[9], const double
     P->f = f; P->cx = cx; P->cy = cy;
     P->t0 = prec[0]; P->tm = prec[1]; P->tu = prec[2]; P->tv = prec[3];
     P->Himg = Himg; P->Wimg = Wimg; P->pts_f64 = pts_f64 ? 1 : 0;
+    return PB3D_OK;
+}
+
+int pb3d_project_keys_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_t* d_cols, int64_t n, int64_t index_base,
+                          const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4], int Himg, int Wimg,
+                          uint64_t* d_keys) {
+    PB3D_REQUIRE(ctx && R && cam && prec && n >= 0 && index_base >= 0 && Himg >= 0 && Wimg >= 0, "pb3d_project_keys: bad argument");
+    PB3D_REQUIRE(index_base + n < (1ll << 39), "pb3d_project_keys: point index does not fit the key");
+    const i64 npix = (i64)Himg * Wimg;
+    if (npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_keys && (n == 0 || (d_pts && d_cols)), "pb3d_project_keys: null buffer");
+    ProjParams P;
+    PB3D_TRY(fill_proj(&P, pts_f64, R, cam, f, cx, cy, prec, Himg, Wimg));
+    PB3D_HIP(hipMemsetAsync(d_keys, 0, (size_t)npix * sizeof(uint64_t), ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_project_keys, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_pts, d_cols, n, index_base, P,
+                           (unsigned long long*)d_keys);
+        PB3D_CHECK_LAUNCH();
+    }
+    return PB3D_OK;
+}
+
+int pb3d_project_resolve_keys_dev(pb3d_ctx* ctx, const uint64_t* d_keys, int Himg, int Wimg, uint8_t* d_img) {
+    PB3D_REQUIRE(ctx && Himg >= 0 && Wimg >= 0, "pb3d_project_resolve_keys: bad argument");
+    const i64 npix = (i64)Himg * Wimg;
+    if (npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_keys && d_img, "pb3d_project_resolve_keys: null buffer");
+    hipLaunchKernelGGL(k_resolve_keys, dim3(pb3d_stream_blocks(ctx, npix, 256, 8)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)d_keys, d_img, npix);
+    PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
 

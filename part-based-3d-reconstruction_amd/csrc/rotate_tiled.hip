@@ -376,7 +376,6 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
         u32 d[16];
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
-        u32 srcok[4] = {0, 0, 0, 0};   // per row i: bit q set iff occupancy byte non-zero ... filled below
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const i64 x = x0 + 4 * xg + i;
@@ -393,7 +392,6 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
                     k16 &= vb[i];
                 }
             }
-            srcok[i] = k16;
             keepb[(4 * xg + i) * 8 + zg] = (unsigned short)k16;
         }
         __syncthreads();

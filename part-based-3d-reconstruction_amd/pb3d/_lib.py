@@ -86,6 +86,9 @@ _SIGNATURES = {
     "pb3d_comm_init": [vp, u8p, C.c_int, C.c_int],
     "pb3d_allgather_dev": [vp, vp, vp, C.c_size_t],
     "pb3d_comm_destroy": [vp],
+    "pb3d_project_keys_dev": [vp, vp, C.c_int, vp, i64, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],
+    "pb3d_project_resolve_keys_dev": [vp, vp, C.c_int, C.c_int, vp],
+    "pb3d_allreduce_max_u64_dev": [vp, vp, C.c_size_t],
 }
 _RESTYPES = {"pb3d_last_error": C.c_char_p, "pb3d_destroy": None, "pb3d_event_destroy": None}
 

@@ -52,8 +52,46 @@ def comm_destroy():
     _lib.check(_lib.load().pb3d_comm_destroy(_lib.ctx()))
 
 
-def carve_sharded_reference_layout(carve_slab, gather, W, rank, nranks):
-    """Host-level description of the sharded carve used by the CPU (gloo) tests and bench.py:
-    carve_slab(x0, x1) -> this rank's carved slab; gather(slab) -> full volume."""
-    x0, x1 = slab_bounds(W, rank, nranks)
-    return gather(carve_slab(x0, x1))
+def point_shard_bounds(n_points, rank, nranks):
+    """[i0, i1) of rank's contiguous share of a point list (same dealing rule as slab_bounds)."""
+    return slab_bounds(n_points, rank, nranks)
+
+
+def project_colored_voxels_sharded(pts_shard, colors_shard, index_base, cam_pos, target, f, cx, cy, H, W, reduce=True):
+    """project_colored_voxels (reference utils/projection_utils.py:5-23) with the point list partitioned over the ranks:
+    `pts_shard` / `colors_shard` are this rank's contiguous range starting at global index `index_base`.  Each rank
+    scatters into a private image of (index, colour) keys; ONE all-reduce(max) merges them and every rank resolves
+    the same (H,W,3) image the unsharded call returns.  reduce=False skips the collective (single rank, or a caller
+    that merges key images itself) and returns (image, keys)."""
+    import ctypes as C
+    import numpy as np
+    from . import device as dev
+    from .projection_utils import camera_args
+    p, pf64, R, cam, prec = camera_args(pts_shard, cam_pos, target, f, cx, cy)
+    cols = np.ascontiguousarray(np.asarray(colors_shard).astype(np.uint8, copy=False))
+    if cols.shape != (len(p), 3):
+        raise ValueError("colors must be (N,3)")
+    lib, ctx = _lib.load(), _lib.ctx()
+    d_p = dev.from_numpy(p) if len(p) else None
+    d_c = dev.from_numpy(cols) if len(p) else None
+    d_keys = dev.DeviceBuffer(int(H) * int(W) * 8); d_img = dev.DeviceBuffer(int(H) * int(W) * 3)
+    try:
+        _lib.check(lib.pb3d_project_keys_dev(ctx, None if d_p is None else C.c_void_p(d_p.ptr), pf64, None if d_c is None else C.c_void_p(d_c.ptr),
+                                             len(p), int(index_base), _lib.p_dbl(R), _lib.p_dbl(cam), float(f), float(cx), float(cy), prec,
+                                             int(H), int(W), C.c_void_p(d_keys.ptr)))
+        if reduce:
+            _lib.check(lib.pb3d_allreduce_max_u64_dev(ctx, C.c_void_p(d_keys.ptr), int(H) * int(W)))
+        _lib.check(lib.pb3d_project_resolve_keys_dev(ctx, C.c_void_p(d_keys.ptr), int(H), int(W), C.c_void_p(d_img.ptr)))
+        img = d_img.download((int(H), int(W), 3))
+        return img if reduce else (img, d_keys.download((int(H), int(W)), np.uint64))
+    finally:
+        for b in (d_p, d_c, d_keys, d_img):
+            if b is not None:
+                b.free()
+
+
+def resolve_keys(keys):
+    """(H,W) uint64 key image -> (H,W,3) uint8 colours (host helper for callers that merged key images themselves)."""
+    import numpy as np
+    k = np.asarray(keys, np.uint64)
+    return np.stack([(k & np.uint64(0xff)), (k >> np.uint64(8)) & np.uint64(0xff), (k >> np.uint64(16)) & np.uint64(0xff)], axis=-1).astype(np.uint8)

@@ -51,13 +51,34 @@ def _worker(rank, world, port, q):
         # (c) uneven partition (S=31 planes over 2 ranks): bounds still tile the axis exactly
         b = [slab_bounds(31, r, world) for r in range(world)]
         ok_c = b[0][0] == 0 and b[-1][1] == 31 and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        # (e) points partition of the projection: per-rank key images ((global index + 1) << 24 | rgb), ONE all_reduce(MAX),
+        #     local resolve == the unsharded projection (last writer wins)
+        rng = np.random.default_rng(5)
+        N = 4000
+        pts = rng.integers(0, 12, (N, 3)).astype(np.float32); cols = rng.integers(0, 256, (N, 3), dtype=np.uint8)
+        cam = np.array([6, 5, -30], np.float32); tgt = np.array([6, 6, 6], np.float32)
+        Hh, Ww = 40, 48
+        want = orc.project_colored_voxels(pts, cols, cam, tgt, 80.0, 24.0, 20.0, Hh, Ww)
+        from pb3d.dist import point_shard_bounds, resolve_keys
+        i0, i1 = point_shard_bounds(N, rank, world)
+        keys = np.zeros((Hh, Ww), np.int64)
+        for i in range(i0, i1):     # the shard's points one by one: which pixel each hits (oracle, single point)
+            one = orc.project_colored_voxels(pts[i:i + 1], np.full((1, 3), 255, np.uint8), cam, tgt, 80.0, 24.0, 20.0, Hh, Ww)
+            hit = np.argwhere(one.any(-1))
+            if len(hit):
+                v, u = hit[0]
+                key = ((i + 1) << 24) | (int(cols[i, 2]) << 16) | (int(cols[i, 1]) << 8) | int(cols[i, 0])
+                keys[v, u] = max(keys[v, u], key)
+        tk = torch.from_numpy(keys)
+        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        ok_e = np.array_equal(resolve_keys(tk.numpy().astype(np.uint64)), want)
         # (d) max-over-ranks timing reduction used by bench.py
         t = torch.tensor([0.25 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ok_d = float(t) == 0.25 + world - 1
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, ok_a, ok_b, ok_c, ok_d))
+        q.put((rank, ok_a, ok_b, ok_c, ok_d and ok_e))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "error", traceback.format_exc(), str(e), None))

@@ -472,3 +472,29 @@ def test_camera_objective_and_zbuffer_n45(pb3d_gpu, mon):
         ppts, _ = pb3d_gpu.get_voxel_points_by_parts(grid, PC, ["front_minarets"])
         vis = pb3d_gpu.project_part_visible(ppts, cam, zbuf, m["H"], m["W"])
         assert vis.dtype == bool and np.array_equal(vis, g[f"vis_{mon}_{mode}"])
+
+
+def test_sharded_projection_keys(pb3d_gpu, oracle):
+    """points partition: shards projected independently into key images, merged by max (what the RCCL
+    all-reduce does), resolve == the unsharded projection; and the same through RCCL on a 1-rank communicator."""
+    from pb3d import dist
+    rng = np.random.default_rng(41)
+    N = 150000
+    pts = rng.integers(0, 24, (N, 3)).astype(np.float32)           # many collisions
+    cols = rng.integers(0, 256, (N, 3), dtype=np.uint8)
+    cam = np.array([12, 10, -60], np.float32); tgt = np.array([12, 12, 12], np.float32)
+    args = (cam, tgt, 150.0, 48.0, 40.0, 80, 96)
+    want = oracle.project_colored_voxels(pts, cols, *args)
+    assert np.array_equal(pb3d_gpu.project_colored_voxels(pts, cols, *args), want)
+    for nr in (2, 3, 8):
+        merged = np.zeros((80, 96), np.uint64)
+        for r in range(nr):
+            i0, i1 = dist.point_shard_bounds(N, r, nr)
+            img_r, keys_r = dist.project_colored_voxels_sharded(pts[i0:i1], cols[i0:i1], i0, *args, reduce=False)
+            merged = np.maximum(merged, keys_r)
+        assert np.array_equal(dist.resolve_keys(merged), want), nr
+    dist.comm_init(dist.new_unique_id(), 0, 1)
+    try:
+        assert np.array_equal(dist.project_colored_voxels_sharded(pts, cols, 0, *args), want)
+    finally:
+        dist.comm_destroy()
