@@ -151,12 +151,20 @@ template <int TYC>
 __global__ __launch_bounds__(256) void k_global_carve90v(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3,
                                                          u8* __restrict__ out_slab, const u32* __restrict__ vbits, int nw, int c0,
                                                          i64 W, i64 H, i64 D, i64 x_first, i64 x_last) {
-    extern __shared__ u8 rows[];  // TYC image rows of W bytes
+    extern __shared__ __attribute__((aligned(16))) u8 rows[];  // TYC image rows of W bytes
     const int lane = threadIdx.x & 63;
     const i64 x = x_first + (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const i64 y_beg = (i64)blockIdx.y * TYC;
     const i64 y_end = y_beg + TYC < H ? y_beg + TYC : H;
-    for (i64 i = threadIdx.x; i < (y_end - y_beg) * W; i += 256) rows[i] = bin_hw[y_beg * W + i] ? 1 : 0;
+    {   // stage the image rows of this y-chunk (raw mask bytes; every use tests != 0), 16 bytes per lane when aligned
+        const i64 nb = (y_end - y_beg) * W;
+        const u8* srcp = bin_hw + y_beg * W;
+        if ((W & 15) == 0 && (((uintptr_t)srcp) & 15u) == 0) {
+            for (i64 i = threadIdx.x; i < nb / 16; i += 256) ((u32x4*)rows)[i] = ((const u32x4*)srcp)[i];
+        } else {
+            for (i64 i = threadIdx.x; i < nb; i += 256) rows[i] = srcp[i];
+        }
+    }
     __syncthreads();
     if (x >= x_last) return;
     const i64 npieces = 3 * D / 16;
@@ -255,14 +263,26 @@ __global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __
         const i64 x = x0 + 4 * xg + i;
         vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
     }
+    // Everything a plane needs from global memory is issued together, one plane ahead: the four 16-byte source
+    // pieces, the source-row mask bytes (applied when the data lands, so the two loads are not dependent) and the
+    // destination-row mask bytes.
     u32x4 stg[4];
+    u8 ms[4], md[4];
     auto load_plane = [&](i64 y) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
             stg[j] = (u32x4)(0u);
-            if (col_ok && n0 >= 0 && n0 < W && (!mask_src || mask_src[n0 * H + y]))
+            ms[j] = 0;
+            if (col_ok && n0 >= 0 && n0 < W) {
                 stg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
+                ms[j] = mask_src ? mask_src[n0 * H + y] : (u8)1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            md[i] = (x < W && vb[i]) ? (mask_dst ? mask_dst[x * H + y] : (u8)1) : (u8)0;
         }
     };
     load_plane(y_beg);
@@ -270,8 +290,11 @@ __global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lr = (tid >> 3) + 32 * j;
-            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = stg[j];
+            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ms[j] ? stg[j] : (u32x4)(0u);
         }
+        u8 mdc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mdc[i] = md[i];
         __syncthreads();
         if (y + 1 < y_end) load_plane(y + 1);
         u32 d[16];
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __
             const i64 x = x0 + 4 * xg + i;
             if (x >= W || zo >= D) continue;
             u32x4 r = (u32x4)(0u);
-            if (vb[i] && (!mask_dst || mask_dst[x * H + y])) {
+            if (mdc[i]) {
                 r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
                 if (vb[i] != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
                     u32 mw[4];
@@ -350,6 +373,7 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
     const i64 row_bytes = ((D - z0 < 128 ? D - z0 : 128)) * 3;   // bytes of one output row inside this tile
     u32x4 stg[4];
     u32 stg_a = 0;
+    u32 stg_d[4] = {0, 0, 0, 0};
     auto load_plane = [&](i64 y) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -361,6 +385,11 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
             const i64 n0 = rbase + tid;
             stg_a = (n0 >= 0 && n0 < W) ? A[n0 * H + y] : 0u;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            stg_d[i] = (x < W && vb[i]) ? A[x * H + y] : 0u;
+        }
     };
     load_plane(y_beg);
     for (i64 y = y_beg; y < y_end; ++y) {
@@ -370,6 +399,9 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
             *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = stg[j];
         }
         if (tid < 128) asrc[tid] = stg_a;
+        u32 adstv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) adstv[i] = stg_d[i];
         __syncthreads();
         if (y + 1 < y_end) load_plane(y + 1);
         // ---- phase A: keep bits of this thread's 4 rows x 16 z
@@ -381,7 +413,7 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
             const i64 x = x0 + 4 * xg + i;
             u32 k16 = 0;
             if (x < W && vb[i]) {
-                const u32 adst = A[x * H + y];
+                const u32 adst = adstv[i];
                 if (adst) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
