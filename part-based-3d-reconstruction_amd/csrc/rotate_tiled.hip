@@ -346,6 +346,23 @@ __global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __
 // loaded from `colored`, masked (alignbyte patterns at the piece's RGB phase) and stored with 128
 // contiguous bytes per 8 lanes.  Rows whose keep bits are all zero are never read.
 // ------------------------------------------------------------------------------------------------
+// 16 occupancy bytes (0/1) of 16 RGB voxels held in 12 dwords
+__device__ __forceinline__ u32x4 occ16_of(const u32x4 a, const u32x4 b, const u32x4 c) {
+    const u32 w[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, 0u};
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+        const u32 v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], (u32)sh) & 0x00ffffffu;
+        o[i >> 2] |= (v ? 1u : 0u) << (8 * (i & 3));
+    }
+    u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+    return r;
+}
+
+// RGBSRC: the source occupancy any(colored > 0) is formed on the fly from the colour grid itself (3 B/voxel read)
+// instead of from a separate occupancy volume.
+template <bool RGBSRC>
 __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, const u8* __restrict__ occ, const u32* __restrict__ A,
                                                 const u32* __restrict__ vbits, int nw, int c0, int c2, i64 W, i64 H, i64 D, int TY,
                                                 u8* __restrict__ out) {
@@ -371,15 +388,21 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
         vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
     }
     const i64 row_bytes = ((D - z0 < 128 ? D - z0 : 128)) * 3;   // bytes of one output row inside this tile
-    u32x4 stg[4];
+    u32x4 stg[RGBSRC ? 12 : 4];
     u32 stg_a = 0;
     u32 stg_d[4] = {0, 0, 0, 0};
     auto load_plane = [&](i64 y) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
-            stg[j] = (u32x4)(0u);
-            if (col_ok && n0 >= 0 && n0 < W) stg[j] = *(const u32x4*)(occ + (n0 * H + y) * D + scol);
+            const bool ok = col_ok && n0 >= 0 && n0 < W;
+            if (RGBSRC) {
+                const u32x4* sp = (const u32x4*)(colored + ((n0 * H + y) * D + scol) * 3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) stg[3 * j + k] = ok ? sp[k] : (u32x4)(0u);
+            } else {
+                stg[j] = ok ? *(const u32x4*)(occ + (n0 * H + y) * D + scol) : (u32x4)(0u);
+            }
         }
         if (tid < 128) {
             const i64 n0 = rbase + tid;
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lr = (tid >> 3) + 32 * j;
-            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = stg[j];
+            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = RGBSRC ? occ16_of(stg[3 * j], stg[3 * j + 1], stg[3 * j + 2]) : stg[j];
         }
         if (tid < 128) asrc[tid] = stg_a;
         u32 adstv[4];
@@ -598,8 +621,12 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     u32* bits; int nw;
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-    void *occ, *A, *jon;
-    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)(W * H * D), &occ));
+    void *occ = nullptr, *A, *jon;
+#ifndef PB3D_PART90_RGBSRC
+#define PB3D_PART90_RGBSRC 1
+#endif
+    const bool rgbsrc = PB3D_PART90_RGBSRC != 0;
+    if (!rgbsrc) PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)(W * H * D), &occ));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)(W * H) * sizeof(u32), &A));
     PB3D_TRY(pb3d_scratch(ctx, 6, 64 * sizeof(int), &jon));
     int on[32];
@@ -609,13 +636,17 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     hipLaunchKernelGGL(k_job_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, d_mask_carve,
                        (const int*)jon, njobs, W * H, (u32*)A);
     PB3D_CHECK_LAUNCH();
-    PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
+    if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
     int TY = 32;
     const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
     while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
     dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
-    hipLaunchKernelGGL(k_part90, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw, pm.c0,
-                       pm.c2, W, H, D, TY, d_out);
+    if (rgbsrc)
+        hipLaunchKernelGGL(k_part90<true>, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw,
+                           pm.c0, pm.c2, W, H, D, TY, d_out);
+    else
+        hipLaunchKernelGGL(k_part90<false>, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw,
+                           pm.c0, pm.c2, W, H, D, TY, d_out);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
