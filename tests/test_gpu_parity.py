@@ -498,3 +498,19 @@ def test_sharded_projection_keys(pb3d_gpu, oracle):
         assert np.array_equal(dist.project_colored_voxels_sharded(pts, cols, 0, *args), want)
     finally:
         dist.comm_destroy()
+
+
+def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
+    """grids above 2^21 voxels take the LDS-tiled lookup-table kernel for generic angles; 0/1 data stays on the table
+    path, 0..255 data must raise the device flag and be redone by the arithmetic kernel -- both bit-exact."""
+    rng = np.random.default_rng(43)
+    for (W, H, D) in [(160, 90, 160), (200, 60, 180), (131, 128, 130)]:
+        m = rng.random((H, W)) < 0.9
+        g_bin = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
+        g_full = rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+        g_one_big = g_bin.copy(); g_one_big[W // 2, H // 2, D // 2] = 200      # a single value > 1 must switch the whole step
+        for ai in (45, 30, 50):
+            for g in (g_bin, g_full, g_one_big):
+                got = pb3d_gpu.process_voxel_grid(g, m, ai)
+                want = oracle.process_voxel_grid(g, m, ai)
+                assert np.array_equal(got, want), (W, H, D, ai, int((got != want).sum()))
