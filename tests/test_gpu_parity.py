@@ -514,3 +514,27 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
                 got = pb3d_gpu.process_voxel_grid(g, m, ai)
                 want = oracle.process_voxel_grid(g, m, ai)
                 assert np.array_equal(got, want), (W, H, D, ai, int((got != want).sum()))
+
+
+def test_random_shapes_property(pb3d_gpu, oracle):
+    """seeded random sweep over shapes / angle steps / mask densities / value ranges: HIP == oracle, byte for byte."""
+    rng = np.random.default_rng(20261004)
+    pal = np.array(list(oracle.PART_COLORS.values()), np.uint8)
+    for trial in range(60):
+        W, H, D = (int(v) for v in rng.integers(1, 90, 3))
+        if trial % 3 == 0:
+            D = W                                   # cubic in XZ -> the 90-degree permutation paths
+        if trial % 6 == 0:
+            W = D = int(rng.choice([16, 32, 48, 64, 80, 128]))
+        ai = int(rng.choice([90, 90, 90, 60, 45, 30, 15, 10, 120]))
+        g = (rng.random((W, H, D)) < rng.uniform(0.1, 0.9)).astype(np.uint8) if trial % 4 else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+        m = rng.random((H, W)) < rng.uniform(0.3, 1.0)
+        assert np.array_equal(pb3d_gpu.process_voxel_grid(g, m, ai), oracle.process_voxel_grid(g, m, ai)), (trial, W, H, D, ai)
+        col = pal[rng.integers(0, 10, (W, H, D))] * (rng.random((W, H, D, 1)) < 0.7).astype(np.uint8)
+        assert np.array_equal(pb3d_gpu.carve_voxel_grid_with_masks(col, m), oracle.carve_voxel_grid_with_masks(col, m)), (trial, "carve")
+        if trial % 5 == 0:
+            sem = pal[rng.integers(0, 10, (H // 3 + 1, W // 3 + 1))].repeat(3, 0).repeat(3, 1)[:H, :W]
+            jobs = [(["full_building", "dome"], 90), (["plinth"], int(rng.choice([90, 45]))), (["chhatris", "windows"], 90)]
+            assert np.array_equal(pb3d_gpu.part_carve(col, sem, jobs), oracle.part_carve(col, sem, jobs)), (trial, "part_carve", W, H, D)
+            binary = (~np.all(sem == pal[9], axis=-1)).astype(np.uint8)
+            assert np.array_equal(pb3d_gpu.global_carve(binary, sem, 90), oracle.global_carve(binary, sem, 90)), (trial, "global_carve", H, W)
