@@ -63,15 +63,37 @@ __global__ __launch_bounds__(256) void k_points_count(const u8* __restrict__ gri
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// exclusive scan of nb block counts into 64-bit offsets; single block, nb is at most a few 100k.
-__global__ __launch_bounds__(1024) void k_scan_counts(const u32* __restrict__ counts, i64* __restrict__ offsets, i64 nb,
-                                                      i64* __restrict__ total) {
+// Exclusive scan of the nb block counts into 64-bit offsets, three small launches:
+//   k_scan_local : 256 threads scan 1024 counts (one 16-byte load per thread) -> in-segment exclusive offsets + segment totals
+//   k_scan_totals: one block scans the segment totals into 64-bit segment bases (+ grand total)
+//   k_scan_add   : offsets[b] = base[b / 1024] + local[b]
+constexpr int kSeg = 1024;
+
+__global__ __launch_bounds__(256) void k_scan_local(const u32* __restrict__ counts, i64 nb, u32* __restrict__ local, u32* __restrict__ seg_total) {
+    __shared__ u32 wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const i64 i0 = (i64)blockIdx.x * kSeg + 4 * threadIdx.x;
+    u32 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = i0 + k < nb ? counts[i0 + k] : 0u;
+    const u32 mine = c[0] + c[1] + c[2] + c[3];
+    u32 inc = mine;
+    for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 before = inc - mine;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (i0 + k < nb) local[i0 + k] = before; before += c[k]; }
+    if (threadIdx.x == 255) seg_total[blockIdx.x] = before;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_totals(const u32* __restrict__ seg_total, i64 nseg, i64* __restrict__ seg_base, i64* __restrict__ total) {
     __shared__ i64 part[1024];
-    const i64 per = (nb + 1023) / 1024;
-    const i64 b = (i64)threadIdx.x * per;
-    const i64 e = b + per < nb ? b + per : nb;
+    const i64 per = (nseg + 1023) / 1024;
+    const i64 b = (i64)threadIdx.x * per, e = b + per < nseg ? b + per : nseg;
     i64 s = 0;
-    for (i64 i = b; i < e; ++i) s += counts[i];
+    for (i64 i = b; i < e; ++i) s += seg_total[i];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -81,7 +103,11 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const u32* __restrict__ co
     }
     __syncthreads();
     i64 run = part[threadIdx.x];
-    for (i64 i = b; i < e; ++i) { offsets[i] = run; run += counts[i]; }
+    for (i64 i = b; i < e; ++i) { seg_base[i] = run; run += seg_total[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(const u32* __restrict__ local, const i64* __restrict__ seg_base, i64 nb, i64* __restrict__ offsets) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (i64)gridDim.x * blockDim.x) offsets[i] = seg_base[i / kSeg] + local[i];
 }
 
 __global__ __launch_bounds__(256) void k_points_fill(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
@@ -214,15 +240,34 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     __syncthreads();
     const i64 out0 = block_off[blockIdx.x];
     float* po = pts + 3 * out0;
-    for (u32 j = threadIdx.x; j < 3 * total; j += 256) {
-        const u32 pt = j / 3, comp = j - 3 * pt;
-        const i64 li = base + lidx[pt];
-        const i64 a2 = li % p.A2, r = li / p.A2;
-        const i64 val = comp == 0 ? a2 : (comp == 1 ? r % p.A1 : r / p.A1);
-        po[j] = (float)val;
+    const bool small = p.nlat <= 0xffffffffll;     // 32-bit index arithmetic when the grid allows it
+    for (u32 pt = threadIdx.x; pt < total; pt += 256) {
+        i64 a2, a1, a0;
+        if (small) {
+            const u32 li = (u32)(base + lidx[pt]), A2u = (u32)p.A2, A1u = (u32)p.A1;
+            const u32 r = li / A2u;
+            a2 = li - r * A2u; a0 = r / A1u; a1 = r - (u32)a0 * A1u;
+        } else {
+            const i64 li = base + lidx[pt];
+            const i64 r = li / p.A2;
+            a2 = li - r * p.A2; a0 = r / p.A1; a1 = r - a0 * p.A1;
+        }
+        po[3 * pt] = (float)a2; po[3 * pt + 1] = (float)a1; po[3 * pt + 2] = (float)a0;
     }
+    // colours: head bytes up to the first dword boundary of the output, then whole dwords, then the tail
     u8* co = cols + 3 * out0;
-    for (u32 j = threadIdx.x; j < 3 * total; j += 256) co[j] = lcol[j];
+    const u32 nbytes = 3 * total;
+    const u32 head = (u32)((4 - ((uintptr_t)co & 3u)) & 3u);
+    const u32 hb = head < nbytes ? head : nbytes;
+    if (threadIdx.x < hb) co[threadIdx.x] = lcol[threadIdx.x];
+    const u32 ndw = (nbytes - hb) / 4;
+    u32* cw = (u32*)(co + hb);
+    for (u32 k = threadIdx.x; k < ndw; k += 256) {
+        const u8* l = lcol + hb + 4 * k;
+        cw[k] = (u32)l[0] | ((u32)l[1] << 8) | ((u32)l[2] << 16) | ((u32)l[3] << 24);
+    }
+    const u32 tail0 = hb + 4 * ndw;
+    if (threadIdx.x < nbytes - tail0) co[tail0 + threadIdx.x] = lcol[tail0 + threadIdx.x];
 }
 
 int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, int stride, SelParams* p) {
@@ -265,8 +310,21 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
     else hipLaunchKernelGGL(k_points_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
     PB3D_CHECK_LAUNCH();
     i64* total = (i64*)offsets + nb;
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)counts, (i64*)offsets, nb, total);
-    PB3D_CHECK_LAUNCH();
+    {
+        const i64 nseg = (nb + kSeg - 1) / kSeg;
+        void *local, *segs;
+        PB3D_TRY(pb3d_scratch(ctx, 11, (size_t)nb * sizeof(u32), &local));
+        PB3D_TRY(pb3d_scratch(ctx, 15, 64 + (size_t)nseg * (sizeof(u32) + sizeof(i64)), &segs));
+        i64* seg_base = (i64*)((u8*)segs + 64);                    // [0,64): the rotate kernels' flag word lives in this slot
+        u32* seg_total = (u32*)(seg_base + nseg);
+        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nseg), dim3(256), 0, ctx->stream, (const u32*)counts, nb, (u32*)local, seg_total);
+        PB3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)seg_total, nseg, seg_base, total);
+        PB3D_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_scan_add, dim3(pb3d_stream_blocks(ctx, nb, 256, 8)), dim3(256), 0, ctx->stream, (const u32*)local,
+                           (const i64*)seg_base, nb, (i64*)offsets);
+        PB3D_CHECK_LAUNCH();
+    }
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));
     *n = *(i64*)ctx->pinned;

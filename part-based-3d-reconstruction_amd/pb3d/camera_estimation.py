@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["compute_partwise_iou", "CameraObjective"]
+__all__ = ["compute_partwise_iou", "CameraObjective", "projection_iou_by_part"]
 
 
 def partwise_iou_counts(proj_mask, gt_mask, colors):
@@ -102,3 +102,54 @@ class CameraObjective:
         for b in (self._d_pts, self._d_cols, self._d_seg, self._d_img):
             if b is not None:
                 b.free()
+
+
+def projection_iou_by_part(voxel_grid, part_colors, image, cam_params):
+    """The numbers behind visualize_voxel_projection_iou (reference utils/camera_estimation.py:381-403, :437-452): for every
+    part its points are extracted, projected with the camera and compared with the part's pixels of `image`; the
+    combined binary IoU compares the union of the projections with every non-background pixel.
+    Returns ({part: IoU}, combined_binary_IoU).  The grid is uploaded once and all parts are processed on the device."""
+    from . import device as dev
+    from .projection_utils import camera_args
+    grid = _lib.as_u8(voxel_grid, "voxel_grid")
+    img = _lib.as_u8(image, "image")
+    H, W = img.shape[:2]
+    A0, A1, A2 = grid.shape[:3]
+    lib, ctx = _lib.load(), _lib.ctx()
+    d_grid = dev.from_numpy(grid); d_img = dev.from_numpy(img); d_proj = dev.DeviceBuffer(H * W * 3)
+    bufs = [d_grid, d_img, d_proj]
+    per = {}
+    union_prj = np.zeros((H, W), bool)
+    try:
+        _, _, R, cam, prec = camera_args(np.zeros((1, 3), np.float32), cam_params["cam_pos"], cam_params["target"], cam_params["f"],
+                                         cam_params["cx"], cam_params["cy"])
+        for part, color in part_colors.items():
+            c = np.asarray(color).reshape(-1)
+            if c.size != 3 or np.any(c < 0) or np.any(c > 255):
+                continue
+            c8 = np.ascontiguousarray(c.astype(np.uint8))
+            n = C.c_int64(0)
+            _lib.check(lib.pb3d_points_count_dev(ctx, C.c_void_p(d_grid.ptr), A0, A1, A2, 3, _lib.p_u8(c8), 1, 1, C.byref(n)))
+            if n.value == 0:
+                continue
+            d_pts = dev.DeviceBuffer(n.value * 12); d_pc = dev.DeviceBuffer(n.value * 3)
+            try:
+                _lib.check(lib.pb3d_points_fill_dev(ctx, C.c_void_p(d_grid.ptr), A0, A1, A2, 3, _lib.p_u8(c8), 1, 1, n.value,
+                                                    C.c_void_p(d_pts.ptr), C.c_void_p(d_pc.ptr)))
+                _lib.check(lib.pb3d_project_dev(ctx, C.c_void_p(d_pts.ptr), 0, C.c_void_p(d_pc.ptr), n.value, _lib.p_dbl(R), _lib.p_dbl(cam),
+                                                float(cam_params["f"]), float(cam_params["cx"]), float(cam_params["cy"]), prec, H, W,
+                                                C.c_void_p(d_proj.ptr)))
+                inter = np.zeros(1, np.int64); uni = np.zeros(1, np.int64)
+                _lib.check(lib.pb3d_partwise_iou_dev(ctx, C.c_void_p(d_proj.ptr), C.c_void_p(d_img.ptr), H * W, _lib.p_u8(c8), 1,
+                                                     inter.ctypes.data_as(_lib.i64p), uni.ctypes.data_as(_lib.i64p)))
+                per[part] = (inter[0] / uni[0]) if uni[0] > 0 else 0.0
+                union_prj |= np.all(d_proj.download((H, W, 3)) == c8, axis=-1)
+            finally:
+                d_pts.free(); d_pc.free()
+        bg = np.array(part_colors.get("background", (0, 0, 0)), dtype=np.uint8)
+        gt = np.any(img != bg, axis=-1)
+        u = np.logical_or(gt, union_prj).sum()
+        return per, ((np.logical_and(gt, union_prj).sum() / u) if u > 0 else 0.0)
+    finally:
+        for b in bufs:
+            b.free()

@@ -538,3 +538,17 @@ def test_random_shapes_property(pb3d_gpu, oracle):
             assert np.array_equal(pb3d_gpu.part_carve(col, sem, jobs), oracle.part_carve(col, sem, jobs)), (trial, "part_carve", W, H, D)
             binary = (~np.all(sem == pal[9], axis=-1)).astype(np.uint8)
             assert np.array_equal(pb3d_gpu.global_carve(binary, sem, 90), oracle.global_carve(binary, sem, 90)), (trial, "global_carve", H, W)
+
+
+def test_reprojection_iou_config3(pb3d_gpu):
+    """BASELINE config 3 as the reference implements it: Charminar stored grid, front and aerial stored cameras,
+    per-part points -> projection -> IoU, i.e. the numbers visualize_voxel_projection_iou puts in its plot titles."""
+    summ = json.load(open(os.path.join(GOLDEN, "f7_projection_summary.json")))
+    g = np.load(os.path.join(GOLDEN, "f7_projection.npz"))
+    grid = np.load(os.path.join(GOLDEN, "stored_Charminar_voxel_grid.npz"))["voxel_grid"]
+    cams = _cams("Charminar")
+    for view in ("front", "drone"):
+        per, combined = pb3d_gpu.projection_iou_by_part(grid, pb3d_gpu.PART_COLORS, g[f"img_Charminar_{view}"], cams[view])
+        for part in ("full_building", "front_minarets", "back_minarets"):
+            assert float(per[part]) == summ[f"Charminar_{view}_part_{part}"], (view, part)
+        assert 0.0 < combined <= 1.0
