@@ -104,6 +104,15 @@ def main():
         args.no_allgather = True
 
     import pb3d
+    if not os.path.exists(pb3d._lib.LIB_PATH):      # fresh checkout: compile the HIP extension in tree first (rank 0 only)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(pb3d._lib.LIB_PATH):
+                    break
+                time.sleep(1)
     from pb3d import device as dev
     from pb3d import dist as pdist
     from pb3d.rendezvous import ControlPlane
