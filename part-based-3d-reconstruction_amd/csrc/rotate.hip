@@ -253,6 +253,162 @@ __global__ __launch_bounds__(256, LUT_WAVES) void k_rotate_lut(const u8* __restr
     if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bit-sliced form of k_rotate_lut: EIGHT Y-planes per pass.  The source position of a cell is the same
+// in every plane, so the staged footprint holds, per source voxel, one byte whose bit p is the 0/1 value
+// of plane y0 + p.  A cell's four taps are then four bytes, and its 16-entry table is applied to all
+// eight planes at once as a 4-level multiplexer tree of bitwise selects (v_bfi_b32):
+//     f = mux(t11, mux(t10, mux(t01, mux(t00, L15, L14), ...), ...), ...)      L_k = table bit k, broadcast
+// -> 4 LDS byte reads + ~31 bit operations per cell per 8 planes, one barrier pair per 8 planes.
+// Packing on the way in: word |= (plane_dword & 0x01010101) << p; unpacking on the way out:
+// (R >> p) & 0x01010101 is the output dword of plane p for the thread's 4 consecutive z.
+// Values > 1 anywhere raise *big_flag exactly as in k_rotate_lut.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 bsel(u32 sel, u32 a, u32 b) { return (sel & a) | (~sel & b); }   // v_bfi_b32
+
+__device__ __forceinline__ u32 lut_apply8(u32 lut, u32 t00, u32 t01, u32 t10, u32 t11) {
+    u32 L[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) L[k] = 0u - ((lut >> k) & 1u);
+    u32 g[8], h[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = bsel(t00, L[2 * j + 1], L[2 * j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = bsel(t01, g[2 * j + 1], g[2 * j]);
+    const u32 m0 = bsel(t10, h[1], h[0]), m1 = bsel(t10, h[3], h[2]);
+    return bsel(t11, m1, m0) & 0xffu;
+}
+
+#ifndef BITS_WAVES
+#define BITS_WAVES 4
+#endif
+constexpr int BPITCH = 128;                       // LDS row pitch of the bit-sliced tile (16-byte units)
+constexpr int BROWS = 100;
+constexpr int BMAXU = (BROWS * (BPITCH / 16) + 255) / 256;   // 16-byte staging units per thread
+
+__global__ __launch_bounds__(256, BITS_WAVES) void k_rotate_bits(const u8* __restrict__ in, u8* __restrict__ out,
+                                                                 const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D, int TY,
+                                                                 int* __restrict__ big_flag) {
+    __shared__ __attribute__((aligned(16))) u8 tile[BROWS * BPITCH];
+    __shared__ int bb[4];
+    const int tid = threadIdx.x;
+    const i64 x0 = (i64)blockIdx.y * LT, z0 = (i64)blockIdx.x * LT;
+    const i64 y_beg = (i64)blockIdx.z * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+    __syncthreads();
+    const int zl = (tid & 3) * 16, xl0 = tid >> 2;   // 16 cells: row xl0, z = zl + 0..15
+    u32 src[16], lut[16];
+    int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const i64 x = x0 + xl0, z = z0 + zl + c;
+        src[c] = 0xffffffffu; lut[c] = 0;
+        if (x < W && z < D) {
+            const Cell cell = make_cell(p, x, z, W, D);
+            if (cell.s0 >= 0) {
+                src[c] = ((u32)cell.s0 << 16) | (u32)cell.s2;
+                lut[c] = lut_of(cell);
+                const int e0 = cell.s0 + (cell.wx1 != 0.0 ? 1 : 0), e2 = cell.s2 + (cell.wz1 != 0.0 ? 1 : 0);
+                mn0 = cell.s0 < mn0 ? cell.s0 : mn0; mx0 = e0 > mx0 ? e0 : mx0;
+                mn2 = cell.s2 < mn2 ? cell.s2 : mn2; mx2 = e2 > mx2 ? e2 : mx2;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (mx0 >= 0) { atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); atomicMin(&bb[2], mn2); atomicMax(&bb[3], mx2); }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1], bz0 = bb[2] & ~15, bz1 = bb[3];   // columns start on a 16-byte boundary
+    const bool any_valid = bx1 >= 0;
+    const int nrows = any_valid ? bx1 - bx0 + 1 : 0;
+    const int nu = any_valid ? (bz1 - bz0) / 16 + 1 : 0;                  // 16-byte units per staged row
+    const bool fits = nrows + 1 <= BROWS && nu * 16 + 4 <= BPITCH + 3 && nu * 16 <= BPITCH;
+    if (any_valid && !fits) { if (tid == 0) atomicOr(big_flag, 1); }
+    u32 cellw[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        u32 o = 0xffffu;
+        if (src[c] != 0xffffffffu && fits) o = (u32)(((int)(src[c] >> 16) - bx0) * BPITCH + ((int)(src[c] & 0xffffu) - bz0));
+        cellw[c] = (lut[c] << 16) | o;
+    }
+    const int nunits = (any_valid && fits) ? nrows * nu : 0;
+    const u32 numagic = nu > 1 ? (u32)(((1ull << 32) + nu - 1) / nu) : 0;
+    const bool al = (D & 15) == 0 && (((uintptr_t)in) & 15u) == 0;       // rows start 16-byte aligned
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    u32 hib = 0;
+    for (i64 yg = y_beg; yg < y_end; yg += 8) {
+        const int np = (int)(y_end - yg < 8 ? y_end - yg : 8);
+        u32 mbits = 0;          // bit q: mask_wh[x, yg + q] of this thread's output row (issued early, consumed after the barrier)
+        {
+            const i64 x = x0 + xl0;
+            if (x < W) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mbits |= (u32)((q < np) && (!mask_wh || mask_wh[x * H + yg + q])) << q;
+            }
+        }
+        // ---- stage the footprint of 8 planes, bit-sliced: one 16-byte piece of 8 planes per step (8 loads in flight)
+#pragma unroll
+        for (int j = 0; j < BMAXU; ++j) {
+            const int i = tid + 256 * j;
+            if (i >= nunits) continue;
+            const int r = nu > 1 ? (int)__umulhi((u32)i, numagic) : i;
+            const int cu = i - r * nu;
+            const i64 col = (i64)bz0 + 16 * cu;
+            const u8* sp = in + (((i64)bx0 + r) * H + yg) * D + col;
+            u32x4 d[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                d[q] = (u32x4)(0u);
+                if (q < np) {
+                    const u8* s8 = sp + (i64)q * D;
+                    if (al && col + 15 < D) d[q] = *(const u32x4*)s8;
+                    else {
+                        u32 t[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < 16; ++b) if (col + b < D) t[b >> 2] |= (u32)s8[b] << (8 * (b & 3));
+                        d[q].x = t[0]; d[q].y = t[1]; d[q].z = t[2]; d[q].w = t[3];
+                    }
+                }
+            }
+            u32x4 wv = (u32x4)(0u);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                wv.x |= (d[q].x & 0x01010101u) << q; wv.y |= (d[q].y & 0x01010101u) << q;
+                wv.z |= (d[q].z & 0x01010101u) << q; wv.w |= (d[q].w & 0x01010101u) << q;
+                hib |= d[q].x | d[q].y | d[q].z | d[q].w;
+            }
+            *(u32x4*)(tile + r * BPITCH + 16 * cu) = wv;
+        }
+        __syncthreads();
+        // ---- evaluate 16 cells x 8 planes, write np planes of this thread's row (16 z = one 16-byte store per plane)
+        {
+            const i64 x = x0 + xl0;
+            if (x < W && z0 + zl < D) {
+                u32 R[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const u32 cw = cellw[c], o = cw & 0xffffu;
+                    if (o == 0xffffu) continue;
+                    R[c >> 2] |= lut_apply8(cw >> 16, tile[o], tile[o + 1], tile[o + BPITCH], tile[o + BPITCH + 1]) << (8 * (c & 3));
+                }
+                for (int q = 0; q < np; ++q) {
+                    const i64 y = yg + q;
+                    const u32 keep = ((mbits >> q) & 1u) ? 0x01010101u : 0u;
+                    u32x4 r;
+                    r.x = (R[0] >> q) & keep; r.y = (R[1] >> q) & keep; r.z = (R[2] >> q) & keep; r.w = (R[3] >> q) & keep;
+                    u8* op = out + (x * H + y) * D + z0 + zl;
+                    if (z0 + zl + 15 < D && (((uintptr_t)op) & 15u) == 0) *(u32x4*)op = r;
+                    else {
+                        const u32 t[4] = {r.x, r.y, r.z, r.w};
+                        for (int b = 0; b < 16; ++b) if (z0 + zl + b < D) op[b] = (u8)(t[b >> 2] >> (8 * (b & 3)));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
+}
+
 bool is_zero(double v) { return v == 0.0; }
 
 }  // namespace
@@ -281,7 +437,13 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
         while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
         dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
         PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
-        hipLaunchKernelGGL(k_rotate_lut, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
+#ifndef PB3D_ROTATE_BITS
+#define PB3D_ROTATE_BITS 1
+#endif
+        if (PB3D_ROTATE_BITS)
+            hipLaunchKernelGGL(k_rotate_bits, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
+        else
+            hipLaunchKernelGGL(k_rotate_lut, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
         PB3D_CHECK_LAUNCH();
     }
     int TY = 16;
