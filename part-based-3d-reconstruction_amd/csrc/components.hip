@@ -95,9 +95,24 @@ __global__ __launch_bounds__(256) void k_ccl_relabel(const int* __restrict__ roo
     }
 }
 
-// per component: bbox (lo inclusive, hi inclusive), voxel count, coordinate sums; wave-aggregated atomics
+// per component: bbox (lo inclusive, hi inclusive), voxel count, coordinate sums.
+// Three levels of aggregation keep the global atomics off the critical path even when one component owns
+// millions of voxels: (1) lanes of a wavefront that share a label are reduced with shuffles, (2) the wave leaders
+// accumulate into a small per-block table in LDS (16 labels, open addressing), (3) the table is flushed with one
+// set of global atomics per label per block.  A label that does not fit the table goes straight to global memory.
+constexpr int kStatSlots = 16;
+
 __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labels, i64 A0, i64 A1, i64 A2, int* __restrict__ bbox,
                                                     unsigned long long* __restrict__ cnt_sum) {
+    __shared__ int slab[kStatSlots];
+    __shared__ int slo[kStatSlots][3], shi[kStatSlots][3];
+    __shared__ unsigned long long scs[kStatSlots][4];
+    if (threadIdx.x < kStatSlots) {
+        slab[threadIdx.x] = 0;
+        for (int a = 0; a < 3; ++a) { slo[threadIdx.x][a] = 0x7fffffff; shi[threadIdx.x][a] = -1; }
+        for (int a = 0; a < 4; ++a) scs[threadIdx.x][a] = 0ull;
+    }
+    __syncthreads();
     const i64 n = A0 * A1 * A2;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     const i64 nloop = (n + stride - 1) / stride;
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labe
         int c[3] = {0, 0, 0};
         if (v < n) {
             L = labels[v];
-            c[2] = (int)(v % A2); const i64 r = v / A2; c[1] = (int)(r % A1); c[0] = (int)(r / A1);
+            if (L > 0) { c[2] = (int)(v % A2); const i64 r = v / A2; c[1] = (int)(r % A1); c[0] = (int)(r / A1); }
         }
         u64 todo = __ballot(L > 0);
         while (todo) {
@@ -115,7 +130,6 @@ __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labe
             const int Lc = __shfl(L, leader);
             const bool mine = L == Lc;
             const u64 grp = __ballot(mine);
-            // reduce over the lanes of this group (all 64 lanes take part in the shuffles)
             int lo[3], hi[3]; long long sm[3];
             for (int a = 0; a < 3; ++a) { lo[a] = mine ? c[a] : 0x7fffffff; hi[a] = mine ? c[a] : -1; sm[a] = mine ? c[a] : 0; }
             for (int off = 32; off > 0; off >>= 1)
@@ -125,14 +139,35 @@ __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labe
                     lo[a] = l2 < lo[a] ? l2 : lo[a]; hi[a] = h2 > hi[a] ? h2 : hi[a]; sm[a] += s2;
                 }
             if ((threadIdx.x & 63) == leader) {
-                int* bb = bbox + 6 * (Lc - 1);
-                for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], lo[a]); atomicMax(&bb[3 + a], hi[a]); }
-                unsigned long long* cs = cnt_sum + 4 * (Lc - 1);
-                atomicAdd(&cs[0], (unsigned long long)__popcll(grp));
-                for (int a = 0; a < 3; ++a) atomicAdd(&cs[1 + a], (unsigned long long)sm[a]);
+                int slot = Lc & (kStatSlots - 1), found = -1;
+                for (int t = 0; t < kStatSlots; ++t) {
+                    const int old = atomicCAS(&slab[slot], 0, Lc);
+                    if (old == 0 || old == Lc) { found = slot; break; }
+                    slot = (slot + 1) & (kStatSlots - 1);
+                }
+                const unsigned long long cnt = (unsigned long long)__popcll(grp);
+                if (found >= 0) {
+                    for (int a = 0; a < 3; ++a) { atomicMin(&slo[found][a], lo[a]); atomicMax(&shi[found][a], hi[a]); }
+                    atomicAdd(&scs[found][0], cnt);
+                    for (int a = 0; a < 3; ++a) atomicAdd(&scs[found][1 + a], (unsigned long long)sm[a]);
+                } else {
+                    int* bb = bbox + 6 * (Lc - 1);
+                    for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], lo[a]); atomicMax(&bb[3 + a], hi[a]); }
+                    unsigned long long* cs = cnt_sum + 4 * (Lc - 1);
+                    atomicAdd(&cs[0], cnt);
+                    for (int a = 0; a < 3; ++a) atomicAdd(&cs[1 + a], (unsigned long long)sm[a]);
+                }
             }
             todo &= ~grp;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && slab[threadIdx.x] > 0) {
+        const int Lc = slab[threadIdx.x];
+        int* bb = bbox + 6 * (Lc - 1);
+        for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], slo[threadIdx.x][a]); atomicMax(&bb[3 + a], shi[threadIdx.x][a]); }
+        unsigned long long* cs = cnt_sum + 4 * (Lc - 1);
+        for (int a = 0; a < 4; ++a) atomicAdd(&cs[a], scs[threadIdx.x][a]);
     }
 }
 

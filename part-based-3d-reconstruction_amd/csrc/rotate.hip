@@ -116,17 +116,14 @@ __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ i
 //    for the tap pattern b = v00 | v01<<1 | v10<<2 | v11<<3 (partial sums formed in SciPy's tap order
 //    from the exact products w_x*w_z; 1.0*w == w and a zero tap adds +0.0, so this IS the reference
 //    arithmetic for 0/1 inputs);
-//  * per plane the rotated footprint (bounding box of the tile's sources incl. the second taps) is
-//    staged into LDS with coalesced dword row loads (next plane prefetched into registers); each
-//    output is then 4 LDS byte reads + one table lookup -- pure integer work in the plane loop;
+//  * the rotated footprint (bounding box of the tile's sources incl. the second taps) is staged into
+//    LDS with coalesced 16-byte row loads and every output becomes LDS reads + a table lookup -- pure
+//    integer work in the plane loop (k_rotate_bits below does this for eight planes at once);
 //  * if ANY staged byte is > 1 the workgroup raises *big_flag: the launcher then lets the arithmetic
 //    kernel k_rotate_generic redo the step (it starts only when the flag is set), so 0..255 grids
 //    stay exact without a host round trip.
 // ------------------------------------------------------------------------------------------------
 constexpr int LT = 64;              // tile edge
-constexpr int LPITCH = 104;         // LDS row pitch (bytes, dword multiple)
-constexpr int LROWS = 100;
-constexpr int LMAXLD = (LROWS * (LPITCH / 4) + 255) / 256;
 
 __device__ __forceinline__ u32 lut_of(const Cell& c) {
     const double p00 = __dmul_rn(c.wx0, c.wz0), p01 = __dmul_rn(c.wx0, c.wz1), p10 = __dmul_rn(c.wx1, c.wz0),
@@ -145,116 +142,8 @@ __device__ __forceinline__ u32 lut_of(const Cell& c) {
     return lut;
 }
 
-#ifndef LUT_WAVES
-#define LUT_WAVES 4
-#endif
-__global__ __launch_bounds__(256, LUT_WAVES) void k_rotate_lut(const u8* __restrict__ in, u8* __restrict__ out,
-                                                       const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D, int TY,
-                                                       int* __restrict__ big_flag) {
-    __shared__ __attribute__((aligned(16))) u8 tile[LROWS * LPITCH];
-    __shared__ int bb[4];
-    const int tid = threadIdx.x;
-    const i64 x0 = (i64)blockIdx.y * LT, z0 = (i64)blockIdx.x * LT;
-    const i64 y_beg = (i64)blockIdx.z * TY;
-    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
-    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
-    __syncthreads();
-    const int zl = (tid & 15) * 4, xl0 = tid >> 4;   // 16 cells: rows xl0 + 16k, z = zl + q
-    u32 src[16];   // s0 << 16 | s2   (0xffffffff: outside)
-    u32 lut[16];
-    int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const i64 x = x0 + xl0 + 16 * (c >> 2), z = z0 + zl + (c & 3);
-        src[c] = 0xffffffffu; lut[c] = 0;
-        if (x < W && z < D) {
-            const Cell cell = make_cell(p, x, z, W, D);
-            if (cell.s0 >= 0) {
-                src[c] = ((u32)cell.s0 << 16) | (u32)cell.s2;
-                lut[c] = lut_of(cell);
-                // second taps are touched only when their weight is non-zero: keep those inside the box
-                const int e0 = cell.s0 + (cell.wx1 != 0.0 ? 1 : 0), e2 = cell.s2 + (cell.wz1 != 0.0 ? 1 : 0);
-                mn0 = cell.s0 < mn0 ? cell.s0 : mn0; mx0 = e0 > mx0 ? e0 : mx0;
-                mn2 = cell.s2 < mn2 ? cell.s2 : mn2; mx2 = e2 > mx2 ? e2 : mx2;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // one cell at a time: keeps the f64 temporaries from piling up
-    }
-    if (mx0 >= 0) { atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); atomicMin(&bb[2], mn2); atomicMax(&bb[3], mx2); }
-    __syncthreads();
-    const int bx0 = bb[0], bx1 = bb[1], bz0 = bb[2] & ~3, bz1 = bb[3];
-    const bool any_valid = bx1 >= 0;
-    const int nrows = any_valid ? bx1 - bx0 + 1 : 0;
-    const int nd = any_valid ? (bz1 - bz0) / 4 + 1 : 0;
-    // +1 row / +1 byte so that zero-weight second taps still read inside the LDS box
-    const bool fits = nrows + 1 <= LROWS && nd * 4 + 4 <= LPITCH;
-    if (any_valid && !fits) { if (tid == 0) atomicOr(big_flag, 1); }   // cannot happen for rotations; fall back exactly
-    u32 cellw[16];   // lut << 16 | LDS offset (0xffff: outside)
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        u32 o = 0xffffu;
-        if (src[c] != 0xffffffffu && fits) o = (u32)(((int)(src[c] >> 16) - bx0) * LPITCH + ((int)(src[c] & 0xffffu) - bz0));
-        cellw[c] = (lut[c] << 16) | o;
-    }
-    const int ndw = (any_valid && fits) ? nrows * nd : 0;
-    const u32 ndmagic = nd > 1 ? (u32)(((1ull << 32) + nd - 1) / nd) : 0;   // i / nd, exact while i * nd < 2^32
-    const bool al = (D & 3) == 0 && (((uintptr_t)in) & 3u) == 0;           // rows start dword-aligned
-    u32 stg[LMAXLD];
-    auto load_plane = [&](i64 y) {
-#pragma unroll
-        for (int j = 0; j < LMAXLD; ++j) {
-            const int i = tid + 256 * j;
-            stg[j] = 0;
-            if (i < ndw) {
-                const int r = nd > 1 ? (int)__umulhi((u32)i, ndmagic) : i;
-                const i64 col = (i64)bz0 + 4 * (i - r * nd);
-                const u8* sp = in + (((i64)bx0 + r) * H + y) * D + col;
-                if (al && col + 3 < D) stg[j] = *(const u32*)sp;
-                else { for (int b = 0; b < 4; ++b) if (col + b < D) stg[j] |= (u32)sp[b] << (8 * b); }
-            }
-        }
-    };
-    load_plane(y_beg);
-    u32 hib = 0;
-    for (i64 y = y_beg; y < y_end; ++y) {
-#pragma unroll
-        for (int j = 0; j < LMAXLD; ++j) {
-            const int i = tid + 256 * j;
-            if (i < ndw) {
-                const int r = nd > 1 ? (int)__umulhi((u32)i, ndmagic) : i;
-                *(u32*)(tile + r * LPITCH + 4 * (i - r * nd)) = stg[j];
-                hib |= stg[j];
-            }
-        }
-        __syncthreads();
-        if (y + 1 < y_end) load_plane(y + 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const i64 x = x0 + xl0 + 16 * k;
-            if (x >= W || z0 + zl >= D) continue;
-            u32 r = 0;
-            if (!mask_wh || mask_wh[x * H + y]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32 cw = cellw[4 * k + q], o = cw & 0xffffu;
-                    if (o == 0xffffu) continue;
-                    // "& 1": a zero-weight second tap may sit on an unstaged (stale) byte; its table bit is a don't-care
-                    const u32 bits = ((u32)tile[o] & 1u) | (((u32)tile[o + 1] & 1u) << 1) | (((u32)tile[o + LPITCH] & 1u) << 2) |
-                                     (((u32)tile[o + LPITCH + 1] & 1u) << 3);
-                    r |= ((cw >> (16 + bits)) & 1u) << (8 * q);
-                }
-            }
-            u8* op = out + (x * H + y) * D + z0 + zl;
-            if (z0 + zl + 3 < D && (((uintptr_t)op) & 3u) == 0) *(u32*)op = r;
-            else { for (int q = 0; q < 4; ++q) if (z0 + zl + q < D) op[q] = (u8)(r >> (8 * q)); }
-        }
-        __syncthreads();
-    }
-    if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Bit-sliced form of k_rotate_lut: EIGHT Y-planes per pass.  The source position of a cell is the same
+// Bit-sliced evaluation: EIGHT Y-planes per pass.  The source position of a cell is the same
 // in every plane, so the staged footprint holds, per source voxel, one byte whose bit p is the 0/1 value
 // of plane y0 + p.  A cell's four taps are then four bytes, and its 16-entry table is applied to all
 // eight planes at once as a 4-level multiplexer tree of bitwise selects (v_bfi_b32):
@@ -262,7 +151,7 @@ __global__ __launch_bounds__(256, LUT_WAVES) void k_rotate_lut(const u8* __restr
 // -> 4 LDS byte reads + ~31 bit operations per cell per 8 planes, one barrier pair per 8 planes.
 // Packing on the way in: word |= (plane_dword & 0x01010101) << p; unpacking on the way out:
 // (R >> p) & 0x01010101 is the output dword of plane p for the thread's 4 consecutive z.
-// Values > 1 anywhere raise *big_flag exactly as in k_rotate_lut.
+// Values > 1 anywhere raise *big_flag: the launcher lets the arithmetic kernel redo the step (see above).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 bsel(u32 sel, u32 a, u32 b) { return (sel & a) | (~sel & b); }   // v_bfi_b32
 
@@ -437,13 +326,7 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
         while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
         dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
         PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
-#ifndef PB3D_ROTATE_BITS
-#define PB3D_ROTATE_BITS 1
-#endif
-        if (PB3D_ROTATE_BITS)
-            hipLaunchKernelGGL(k_rotate_bits, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
-        else
-            hipLaunchKernelGGL(k_rotate_lut, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
+        hipLaunchKernelGGL(k_rotate_bits, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
         PB3D_CHECK_LAUNCH();
     }
     int TY = 16;

@@ -239,10 +239,14 @@ __global__ __launch_bounds__(256) void k_global_carve90b(const u8* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
-__global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
+#ifndef ROT90_WAVES
+#define ROT90_WAVES 4
+#endif
+template <int PP>   // planes per pass: PP tiles staged, one barrier pair per PP planes, PP planes of loads in flight
+__global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
                                                i64 W, i64 H, i64 D, int TY) {
-    __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
+    __shared__ __attribute__((aligned(16))) u8 tiles[PP][128 * 128];
     const int tid = threadIdx.x;
     const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;
     const i64 y_beg = (i64)blockIdx.z * TY;
@@ -263,73 +267,85 @@ __global__ __launch_bounds__(256) void k_rot90(const u8* __restrict__ in, u8* __
         const i64 x = x0 + 4 * xg + i;
         vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
     }
-    // Everything a plane needs from global memory is issued together, one plane ahead: the four 16-byte source
-    // pieces, the source-row mask bytes (applied when the data lands, so the two loads are not dependent) and the
+    // Everything a pass needs from global memory is issued together, one pass ahead: the 16-byte source pieces, the
+    // source-row mask bytes (applied when the data lands, so the two loads are not dependent) and the
     // destination-row mask bytes.
-    u32x4 stg[4];
-    u8 ms[4], md[4];
-    auto load_plane = [&](i64 y) {
+    u32x4 stg[PP][4];
+    u32 msk[PP];       // byte j: source-row mask of piece j ; bits 28..31: destination-row mask of row i
+    auto load_pass = [&](i64 y0p) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const i64 n0 = rbase + (tid >> 3) + 32 * j;
-            stg[j] = (u32x4)(0u);
-            ms[j] = 0;
-            if (col_ok && n0 >= 0 && n0 < W) {
-                stg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
-                ms[j] = mask_src ? mask_src[n0 * H + y] : (u8)1;
-            }
-        }
+        for (int pp = 0; pp < PP; ++pp) {
+            const i64 y = y0p + pp;
+            u32 mk = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 x = x0 + 4 * xg + i;
-            md[i] = (x < W && vb[i]) ? (mask_dst ? mask_dst[x * H + y] : (u8)1) : (u8)0;
-        }
-    };
-    load_plane(y_beg);
-    for (i64 y = y_beg; y < y_end; ++y) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = (tid >> 3) + 32 * j;
-            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ms[j] ? stg[j] : (u32x4)(0u);
-        }
-        u8 mdc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mdc[i] = md[i];
-        __syncthreads();
-        if (y + 1 < y_end) load_plane(y + 1);
-        u32 d[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
-        u32 o[4][4];  // o[i][w]: output x = 4 xg + i, bytes q = 4w .. 4w+3 ; byte q <- d[15 - q].byte[i]
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const u32 A = d[15 - 4 * w], B = d[14 - 4 * w], Cc = d[13 - 4 * w], E = d[12 - 4 * w];
-            const u32 t0 = perm(B, A, 0x05010400u), t1 = perm(B, A, 0x07030602u);
-            const u32 u0 = perm(E, Cc, 0x05010400u), u1 = perm(E, Cc, 0x07030602u);
-            o[0][w] = perm(u0, t0, 0x05040100u);
-            o[1][w] = perm(u0, t0, 0x07060302u);
-            o[2][w] = perm(u1, t1, 0x05040100u);
-            o[3][w] = perm(u1, t1, 0x07060302u);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 x = x0 + 4 * xg + i;
-            if (x >= W || zo >= D) continue;
-            u32x4 r = (u32x4)(0u);
-            if (mdc[i]) {
-                r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
-                if (vb[i] != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
-                    u32 mw[4];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const u32 b4 = (vb[i] >> (4 * w)) & 0xfu;
-                        mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) |
-                                ((b4 & 8u) ? 0xff000000u : 0u);
-                    }
-                    r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
+            for (int j = 0; j < 4; ++j) {
+                const i64 n0 = rbase + (tid >> 3) + 32 * j;
+                stg[pp][j] = (u32x4)(0u);
+                if (y < y_end && col_ok && n0 >= 0 && n0 < W) {
+                    stg[pp][j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
+                    mk |= (u32)((mask_src ? mask_src[n0 * H + y] : (u8)1) != 0) << j;
                 }
             }
-            __builtin_nontemporal_store(r, (u32x4*)(out + (x * H + y) * D + zo));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i64 x = x0 + 4 * xg + i;
+                if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
+            }
+            msk[pp] = mk;
+        }
+    };
+    load_pass(y_beg);
+    for (i64 y0p = y_beg; y0p < y_end; y0p += PP) {
+        u32 mkc[PP];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            mkc[pp] = msk[pp];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lr = (tid >> 3) + 32 * j;
+                *(u32x4*)(tiles[pp] + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ((mkc[pp] >> j) & 1u) ? stg[pp][j] : (u32x4)(0u);
+            }
+        }
+        __syncthreads();
+        if (y0p + PP < y_end) load_pass(y0p + PP);
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const i64 y = y0p + pp;
+            if (y >= y_end) break;
+            u32 d[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tiles[pp] + rd_off + rr * 128);
+            u32 o[4][4];  // o[i][w]: output x = 4 xg + i, bytes q = 4w .. 4w+3 ; byte q <- d[15 - q].byte[i]
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u32 A = d[15 - 4 * w], B = d[14 - 4 * w], Cc = d[13 - 4 * w], E = d[12 - 4 * w];
+                const u32 t0 = perm(B, A, 0x05010400u), t1 = perm(B, A, 0x07030602u);
+                const u32 u0 = perm(E, Cc, 0x05010400u), u1 = perm(E, Cc, 0x07030602u);
+                o[0][w] = perm(u0, t0, 0x05040100u);
+                o[1][w] = perm(u0, t0, 0x07060302u);
+                o[2][w] = perm(u1, t1, 0x05040100u);
+                o[3][w] = perm(u1, t1, 0x07060302u);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i64 x = x0 + 4 * xg + i;
+                if (x >= W || zo >= D) continue;
+                u32x4 r = (u32x4)(0u);
+                if ((mkc[pp] >> (4 + i)) & 1u) {
+                    r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
+                    if (vb[i] != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
+                        u32 mw[4];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const u32 b4 = (vb[i] >> (4 * w)) & 0xfu;
+                            mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) |
+                                    ((b4 & 8u) ? 0xff000000u : 0u);
+                        }
+                        r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
+                    }
+                }
+                __builtin_nontemporal_store(r, (u32x4*)(out + (x * H + y) * D + zo));
+            }
         }
         __syncthreads();
     }
@@ -557,7 +573,10 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
         while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
         dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
-        hipLaunchKernelGGL(k_rot90, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
+#ifndef PB3D_ROT90_PP
+#define PB3D_ROT90_PP 1
+#endif
+        hipLaunchKernelGGL(k_rot90<PB3D_ROT90_PP>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
                            pm.c0, pm.c2, W, H, D, TY);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
