@@ -187,7 +187,15 @@ def main():
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            uid = cp.broadcast(pdist.new_unique_id().tobytes() if rank == 0 else None)
+            uid = None
+            if rank == 0:
+                try:
+                    uid = pdist.new_unique_id().tobytes()
+                except Exception as e:  # noqa: BLE001 - RCCL missing / unusable: tell the other ranks to skip the phase
+                    uid = f"{type(e).__name__}: {e}"
+            uid = cp.broadcast(uid)
+            if not isinstance(uid, bytes):
+                raise RuntimeError(f"rank 0 could not create the RCCL id ({uid})")
             pdist.comm_init(np.frombuffer(uid, np.uint8), rank, world)
             for _ in range(2):
                 pdist.allgather(d_out, d_full, slab_bytes)
