@@ -205,6 +205,71 @@ __global__ __launch_bounds__(256) void k_part_final(const u8* __restrict__ color
     }
 }
 
+// 16-voxel-per-lane forms of the three kernels above (D % 16 == 0, 16-byte aligned buffers): a group of 16 voxels
+// lies in one (x,y) column, so the 2-D mask byte is read once per group and skipped groups cost no grid read.
+__global__ __launch_bounds__(256) void k_part_occ16(const u32x4* __restrict__ colored, const u8* __restrict__ mask_sub,
+                                                    u32x4* __restrict__ occ, i64 ngroups, i64 D16) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        u32 o[4] = {0, 0, 0, 0};
+        if (mask_sub[g / D16]) {
+            u32 w[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const u32x4 t = ld_nt(colored + 3 * g + k); w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const u32 any = byte_of(w, 3 * i) | byte_of(w, 3 * i + 1) | byte_of(w, 3 * i + 2);
+                o[i >> 2] |= (any ? 1u : 0u) << ((i & 3) * 8);
+            }
+        }
+        u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+        st_nt(occ + g, r);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_keep_or16(const u32x4* __restrict__ carved, const u8* __restrict__ mask_sub,
+                                                   u32x4* __restrict__ keep, i64 ngroups, i64 D16, int first) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        u32x4 k = (u32x4)(0u);
+        if (mask_sub[g / D16]) {
+            const u32x4 c = carved[g];
+            // per byte: non-zero -> 1 (carved is 0/1 on this path, but stay exact for any byte value)
+            const u32 cw[4] = {c.x, c.y, c.z, c.w};
+            u32 kw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32 t = cw[j];
+                t |= t >> 4; t |= t >> 2; t |= t >> 1;   // fold every byte's bits into its bit 0
+                kw[j] = t & 0x01010101u;
+            }
+            k.x = kw[0]; k.y = kw[1]; k.z = kw[2]; k.w = kw[3];
+        }
+        if (!first) { const u32x4 old = keep[g]; k.x |= old.x; k.y |= old.y; k.z |= old.z; k.w |= old.w; }
+        keep[g] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_part_final16(const u32x4* __restrict__ colored, const u32x4* __restrict__ keep,
+                                                      u32x4* __restrict__ out, i64 ngroups) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        const u32x4 kv = ld_nt(keep + g);
+        const u32 kw[4] = {kv.x, kv.y, kv.z, kv.w};
+        u32 keep16 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep16 |= (byte_of(kw, i) ? 1u : 0u) << i;
+        u32 m[12];
+        expand16(keep16, 0xffu, 0xffu, 0xffu, m);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32x4 r = (u32x4)(0u);
+            if (keep16) {
+                const u32x4 c = ld_nt(colored + 3 * g + k);
+                r.x = c.x & m[4 * k]; r.y = c.y & m[4 * k + 1]; r.z = c.z & m[4 * k + 2]; r.w = c.w & m[4 * k + 3];
+            }
+            st_nt(out + 3 * g + k, r);
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
@@ -297,16 +362,25 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)nvox, &keep));
     const unsigned blocks = pb3d_stream_blocks(ctx, nvox, 256, 8);
+    const bool wide = (D % 16 == 0) && aligned16(d_colored) && aligned16(d_out);   // scratch buffers are 4 KiB aligned
+    const i64 ngroups = nvox / 16;
+    const unsigned gblocks = pb3d_stream_blocks(ctx, ngroups > 0 ? ngroups : 1, 256, 8);
     bool any = false;
     for (int j = 0; j < njobs; ++j) {
         if (job_skip[j]) continue;
         const u8* ms = d_mask_sub + (i64)j * W * H;
         const u8* mc = d_mask_carve + (i64)j * W * H;
-        hipLaunchKernelGGL(k_part_occ, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D);
+        if (wide)
+            hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, D / 16);
+        else
+            hipLaunchKernelGGL(k_part_occ, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D);
         PB3D_CHECK_LAUNCH();
         PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
-        hipLaunchKernelGGL(k_keep_or, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D,
-                           any ? 0 : 1);
+        if (wide)
+            hipLaunchKernelGGL(k_keep_or16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)carved, ms, (u32x4*)keep, ngroups, D / 16,
+                               any ? 0 : 1);
+        else
+            hipLaunchKernelGGL(k_keep_or, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1);
         PB3D_CHECK_LAUNCH();
         any = true;
     }
@@ -314,7 +388,11 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         PB3D_HIP(hipMemsetAsync(d_out, 0, (size_t)nvox * 3, ctx->stream));
         return PB3D_OK;
     }
-    hipLaunchKernelGGL(k_part_final, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox);
+    if (wide)
+        hipLaunchKernelGGL(k_part_final16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, (const u32x4*)keep, (u32x4*)d_out,
+                           ngroups);
+    else
+        hipLaunchKernelGGL(k_part_final, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
