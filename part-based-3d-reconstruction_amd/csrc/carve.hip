@@ -11,6 +11,35 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+// RGB side of the 16-voxels-per-lane kernels: a lane owns 48 contiguous bytes, so every 128-byte line is touched by three
+// instructions of the wave.  Nontemporal hints make the line leave the L1 between them (measured 1.4x slower on the
+// point sweep of project.hip), so these accesses stay plain.
+#ifndef PB3D_STRIDED_NT
+#define PB3D_STRIDED_NT 0
+#endif
+__device__ __forceinline__ u32x4 ld_s(const u32x4* p) { return PB3D_STRIDED_NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_s(u32x4* p, u32x4 v) { if (PB3D_STRIDED_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// RGB stores of those kernels: the wave's 64 groups form 3 KiB contiguous in the output (vector index 3 * gw0 ...), but a lane
+// holds vectors 3*lane .. 3*lane+2 of it.  Route them through a wave-private LDS window (192 vectors) so that every store
+// instruction writes 1 KiB contiguous (whole 128-byte lines) instead of 16 bytes every 48.  Called by all 64 lanes.
+__device__ __forceinline__ void store48_wave(u32x4* __restrict__ out, i64 gw0, i64 ngroups, const u32x4 r[3], u32x4* lds_w) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lds_w[3 * lane + k] = r[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const i64 left = ngroups - gw0;
+    const int nvec = 3 * (int)(left < 64 ? left : 64);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = lane + 64 * k;
+        if (idx < nvec) st_nt(out + 3 * gw0 + idx, lds_w[idx]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ------------------------------------------------------------------------------------------------
 // K1 fast path: column size col = D*C is a multiple of 16 bytes, buffers 16-byte aligned.
@@ -84,19 +113,38 @@ __global__ __launch_bounds__(256) void k_carve_bytes(const u8* __restrict__ in, 
     }
 }
 
+// The mirror image for loads: the wave reads its 3 KiB with three contiguous 1 KiB instructions into the LDS window and
+// every lane then picks up its own 48 bytes.  Called by all 64 lanes; lanes past the end get zeros.
+__device__ __forceinline__ void load48_wave(const u32x4* __restrict__ in, i64 gw0, i64 ngroups, u32x4 r[3], u32x4* lds_w) {
+    const int lane = threadIdx.x & 63;
+    const i64 left = ngroups - gw0;
+    const int nvec = 3 * (int)(left < 64 ? left : 64);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = lane + 64 * k;
+        lds_w[idx] = idx < nvec ? ld_nt(in + 3 * gw0 + idx) : (u32x4)(0u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = lds_w[3 * lane + k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------------
 // _occupancy: 16 voxels (48 bytes in, 16 bytes out) per thread.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 byte_of(const u32* w, int idx) { return (w[idx >> 2] >> ((idx & 3) * 8)) & 0xffu; }
 
 __global__ __launch_bounds__(256) void k_occupancy16(const u32x4* __restrict__ rgb, u32x4* __restrict__ occ, i64 ngroups) {
-    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
-        u32 w[12];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const u32x4 v = ld_nt(rgb + 3 * g + k);
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        }
+    __shared__ u32x4 stage[4][192];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (i64 gw0 = (i64)blockIdx.x * blockDim.x + 64 * wv; gw0 < ngroups; gw0 += (i64)gridDim.x * blockDim.x) {   // wave-uniform
+        u32x4 v[3];
+        load48_wave(rgb, gw0, ngroups, v, stage[wv]);
+        const u32 w[12] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w};
         u32 o[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -104,7 +152,7 @@ __global__ __launch_bounds__(256) void k_occupancy16(const u32x4* __restrict__ r
             o[i >> 2] |= (any ? 1u : 0u) << ((i & 3) * 8);
         }
         u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
-        st_nt(occ + g, r);
+        if (gw0 + lane < ngroups) st_nt(occ + gw0 + lane, r);
     }
 }
 
@@ -135,22 +183,26 @@ __device__ __forceinline__ void expand16(const u32 keep16, const u32 r, const u3
 
 __global__ __launch_bounds__(256) void k_color_apply16(const u32x4* __restrict__ carved, const u8* __restrict__ rgb_hw3,
                                                        u32x4* __restrict__ out, i64 W, i64 H, i64 D16, i64 ngroups) {
-    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
-        const i64 xy = g / D16;
-        const i64 x = xy / H, y = xy - x * H;
-        const u8* px = rgb_hw3 + (y * W + x) * 3;
-        const u32x4 cv = ld_nt(carved + g);
-        const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
-        u32 keep16 = 0;
+    __shared__ u32x4 stage[4][192];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (i64 gw0 = (i64)blockIdx.x * blockDim.x + 64 * wv; gw0 < ngroups; gw0 += (i64)gridDim.x * blockDim.x) {   // wave-uniform
+        const i64 g = gw0 + lane;
+        u32x4 r[3] = {(u32x4)(0u), (u32x4)(0u), (u32x4)(0u)};
+        if (g < ngroups) {
+            const i64 xy = g / D16;
+            const i64 x = xy / H, y = xy - x * H;
+            const u8* px = rgb_hw3 + (y * W + x) * 3;
+            const u32x4 cv = ld_nt(carved + g);
+            const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
+            u32 keep16 = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) keep16 |= (byte_of(cw, i) == 1u ? 1u : 0u) << i;
-        u32 w[12];
-        expand16(keep16, px[0], px[1], px[2], w);
+            for (int i = 0; i < 16; ++i) keep16 |= (byte_of(cw, i) == 1u ? 1u : 0u) << i;
+            u32 w[12];
+            expand16(keep16, px[0], px[1], px[2], w);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            u32x4 r; r.x = w[4 * k]; r.y = w[4 * k + 1]; r.z = w[4 * k + 2]; r.w = w[4 * k + 3];
-            st_nt(out + 3 * g + k, r);
+            for (int k = 0; k < 3; ++k) { r[k].x = w[4 * k]; r[k].y = w[4 * k + 1]; r[k].z = w[4 * k + 2]; r[k].w = w[4 * k + 3]; }
         }
+        store48_wave(out, gw0, ngroups, r, stage[wv]);
     }
 }
 
@@ -214,7 +266,7 @@ __global__ __launch_bounds__(256) void k_part_occ16(const u32x4* __restrict__ co
         if (mask_sub[g / D16]) {
             u32 w[12];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { const u32x4 t = ld_nt(colored + 3 * g + k); w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
+            for (int k = 0; k < 3; ++k) { const u32x4 t = ld_s(colored + 3 * g + k); w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const u32 any = byte_of(w, 3 * i) | byte_of(w, 3 * i + 1) | byte_of(w, 3 * i + 2);
@@ -250,23 +302,28 @@ __global__ __launch_bounds__(256) void k_keep_or16(const u32x4* __restrict__ car
 
 __global__ __launch_bounds__(256) void k_part_final16(const u32x4* __restrict__ colored, const u32x4* __restrict__ keep,
                                                       u32x4* __restrict__ out, i64 ngroups) {
-    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
-        const u32x4 kv = ld_nt(keep + g);
-        const u32 kw[4] = {kv.x, kv.y, kv.z, kv.w};
-        u32 keep16 = 0;
+    __shared__ u32x4 stage[4][192];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (i64 gw0 = (i64)blockIdx.x * blockDim.x + 64 * wv; gw0 < ngroups; gw0 += (i64)gridDim.x * blockDim.x) {   // wave-uniform
+        const i64 g = gw0 + lane;
+        u32x4 r[3] = {(u32x4)(0u), (u32x4)(0u), (u32x4)(0u)};
+        if (g < ngroups) {
+            const u32x4 kv = ld_nt(keep + g);
+            const u32 kw[4] = {kv.x, kv.y, kv.z, kv.w};
+            u32 keep16 = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) keep16 |= (byte_of(kw, i) ? 1u : 0u) << i;
-        u32 m[12];
-        expand16(keep16, 0xffu, 0xffu, 0xffu, m);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            u32x4 r = (u32x4)(0u);
+            for (int i = 0; i < 16; ++i) keep16 |= (byte_of(kw, i) ? 1u : 0u) << i;
             if (keep16) {
-                const u32x4 c = ld_nt(colored + 3 * g + k);
-                r.x = c.x & m[4 * k]; r.y = c.y & m[4 * k + 1]; r.z = c.z & m[4 * k + 2]; r.w = c.w & m[4 * k + 3];
+                u32 m[12];
+                expand16(keep16, 0xffu, 0xffu, 0xffu, m);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const u32x4 c = ld_s(colored + 3 * g + k);
+                    r[k].x = c.x & m[4 * k]; r[k].y = c.y & m[4 * k + 1]; r[k].z = c.z & m[4 * k + 2]; r[k].w = c.w & m[4 * k + 3];
+                }
             }
-            st_nt(out + 3 * g + k, r);
         }
+        store48_wave(out, gw0, ngroups, r, stage[wv]);
     }
 }
 

@@ -17,7 +17,29 @@ struct SelParams {
     int C, ncolors, stride;
     u8 colors[3 * 32];
     u32 colors32[32];   // the same colours packed r | g << 8 | b << 16
+    // colour-set membership as ONE perfect-hash probe per voxel (stride-1 kernels): entry = bits 31..24 of
+    // mul24(colour, hashK); htab[entry] = colour << 8 for the set's colours, 1 (never equal) elsewhere
+    u32 hashK;
+    u32 htab[256];
+    // exact u32 division by A2 and by A1 (Granlund-Montgomery round-up form): q = (t + ((n - t) >> s1)) >> s2, t = mulhi(m, n)
+    u32 m2, m1;
+    int s2a, s2b, s1a, s1b;
 };
+
+struct Magic { u32 m; int sa, sb; };
+inline Magic make_magic(u32 d) {     // 1 <= d < 2^31
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    Magic g;
+    g.m = (u32)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    g.sa = L < 1 ? L : 1;
+    g.sb = L > 1 ? L - 1 : 0;
+    return g;
+}
+__device__ __forceinline__ u32 magic_div(u32 n, u32 m, int sa, int sb) {
+    const u32 t = __umulhi(m, n);
+    return (t + ((n - t) >> sa)) >> sb;
+}
 
 __device__ __forceinline__ i64 lattice_to_voxel(const SelParams& p, i64 li, i64* i0, i64* i1, i64* i2) {
     if (p.stride == 1) {
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(256) void k_points_fill(const u8* __restrict__ grid
 // ------------------------------------------------------------------------------------------------
 typedef u32 u32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ u32 select16(const SelParams& p, const u8* __restrict__ grid, i64 v0, i64 nvox, u32 w[12]) {
+__device__ __forceinline__ u32 select16(const SelParams& p, const u32* htab, const u8* __restrict__ grid, i64 v0, i64 nvox, u32 w[12]) {
     // loads the 48 bytes of voxels v0..v0+15 (bounds-checked at the grid's end) and returns their 16 select bits
     if (v0 + 16 <= nvox) {
         const u32x4v* g = (const u32x4v*)(grid + 3 * v0);
@@ -173,22 +195,33 @@ __device__ __forceinline__ u32 select16(const SelParams& p, const u8* __restrict
             w[k] = t;
         }
     }
-    u32 vox[16];   // r | g << 8 | b << 16
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = (3 * i) >> 2, sh = (3 * i) & 3;
-        vox[i] = __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) & 0x00ffffffu;
-    }
     u32 bits = 0;
-    if (p.ncolors > 0) {
+    if (p.ncolors > 0 && p.hashK) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+            const u32 v = __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh);   // top byte: the next voxel's red
+            const u32 e = (__umul24(v, p.hashK) >> 22) & 0x3fcu;                                  // mul24 ignores the top byte
+            bits |= (u32)((v << 8) == *(const u32*)((const u8*)htab + e)) << i;
+        }
+    } else if (p.ncolors > 0) {                  // no collision-free multiplier found (practically never): compare loop
+        u32 vox[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+            vox[i] = __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) & 0x00ffffffu;
+        }
         for (int k = 0; k < p.ncolors; ++k) {
-            const u32 ck = p.colors32[k];   // wave-uniform: one scalar load per colour for all 16 voxels
+            const u32 ck = p.colors32[k];
 #pragma unroll
             for (int i = 0; i < 16; ++i) bits |= (u32)(vox[i] == ck) << i;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bits |= (u32)(vox[i] != 0u) << i;
+        for (int i = 0; i < 16; ++i) {
+            const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+            bits |= (u32)((__builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) << 8) != 0u) << i;
+        }
     }
     const i64 left = nvox - v0;
     if (left < 16) bits &= (1u << left) - 1u;
@@ -197,28 +230,35 @@ __device__ __forceinline__ u32 select16(const SelParams& p, const u8* __restrict
 
 __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ grid, SelParams p, u32* __restrict__ block_counts) {
     __shared__ u32 wsum[4];
+    __shared__ u32 htab[256];
+    htab[threadIdx.x] = p.htab[threadIdx.x];
+    __syncthreads();
     const i64 v0 = (i64)blockIdx.x * kBlockVox + 16 * threadIdx.x;
     u32 w[12];
-    u32 c = v0 < p.nlat ? (u32)__popc(select16(p, grid, v0, p.nlat, w)) : 0u;
+    u32 c = v0 < p.nlat ? (u32)__popc(select16(p, htab, grid, v0, p.nlat, w)) : 0u;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// Phase 1: every thread ranks its selected voxels inside the block and drops (local index, colour) into LDS
-// in output order.  Phase 2: the block writes the compacted records with fully coalesced stores (dword j of
-// the points = component j % 3 of point j / 3; colour bytes linear).
+// Phase 1: every thread ranks its selected voxels inside the block and drops (local index, colour) records into LDS
+// in output order.  Phase 2: the block writes the compacted points and colours; coordinates come from the block's
+// base (a0,a1,a2) plus the local index with exact multiply-high divisions (no integer divide in the loop), colour
+// bytes leave as whole dwords cut out of two neighbouring 24-bit records.
 __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
                                                        float* __restrict__ pts, u8* __restrict__ cols) {
     __shared__ u32 wsum[4];
+    __shared__ u32 htab[256];
     __shared__ unsigned short lidx[kBlockVox];
-    __shared__ u8 lcol[kBlockVox * 3];
+    __shared__ u32 lrec[kBlockVox + 1];
+    htab[threadIdx.x] = p.htab[threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const i64 base = (i64)blockIdx.x * kBlockVox;
     const i64 v0 = base + 16 * threadIdx.x;
     u32 w[12];
-    const u32 bits = v0 < p.nlat ? select16(p, grid, v0, p.nlat, w) : 0u;
+    const u32 bits = v0 < p.nlat ? select16(p, htab, grid, v0, p.nlat, w) : 0u;
     const u32 c = (u32)__popc(bits);
     u32 inc = c;
     for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
@@ -230,28 +270,34 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if ((bits >> i) & 1u) {
+            const int j = (3 * i) >> 2, sh = (3 * i) & 3;
             lidx[k] = (unsigned short)(16 * threadIdx.x + i);
-            lcol[3 * k] = (u8)((w[(3 * i) >> 2] >> (((3 * i) & 3) * 8)) & 0xffu);
-            lcol[3 * k + 1] = (u8)((w[(3 * i + 1) >> 2] >> (((3 * i + 1) & 3) * 8)) & 0xffu);
-            lcol[3 * k + 2] = (u8)((w[(3 * i + 2) >> 2] >> (((3 * i + 2) & 3) * 8)) & 0xffu);
+            lrec[k] = __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) & 0x00ffffffu;
             ++k;
         }
     }
     __syncthreads();
     const i64 out0 = block_off[blockIdx.x];
+    // block base -> (b0, b1, b2); uniform, once per thread
+    u32 b2, b1; i64 b0;
+    if (p.nlat <= 0xffffffffll) {
+        const u32 r = magic_div((u32)base, p.m2, p.s2a, p.s2b);
+        b2 = (u32)base - r * (u32)p.A2;
+        const u32 q = magic_div(r, p.m1, p.s1a, p.s1b);
+        b1 = r - q * (u32)p.A1; b0 = q;
+    } else {
+        const i64 r = base / p.A2;
+        b2 = (u32)(base - r * p.A2); b0 = r / p.A1; b1 = (u32)(r - b0 * p.A1);
+    }
     float* po = pts + 3 * out0;
-    const bool small = p.nlat <= 0xffffffffll;     // 32-bit index arithmetic when the grid allows it
     for (u32 pt = threadIdx.x; pt < total; pt += 256) {
-        i64 a2, a1, a0;
-        if (small) {
-            const u32 li = (u32)(base + lidx[pt]), A2u = (u32)p.A2, A1u = (u32)p.A1;
-            const u32 r = li / A2u;
-            a2 = li - r * A2u; a0 = r / A1u; a1 = r - (u32)a0 * A1u;
-        } else {
-            const i64 li = base + lidx[pt];
-            const i64 r = li / p.A2;
-            a2 = li - r * p.A2; a0 = r / p.A1; a1 = r - a0 * p.A1;
-        }
+        const u32 x = b2 + lidx[pt];                               // < A2 + 4096
+        const u32 q2 = magic_div(x, p.m2, p.s2a, p.s2b);
+        const u32 a2 = x - q2 * (u32)p.A2;
+        const u32 y = b1 + q2;                                      // < A1 + 4096
+        const u32 q1 = magic_div(y, p.m1, p.s1a, p.s1b);
+        const u32 a1 = y - q1 * (u32)p.A1;
+        const i64 a0 = b0 + q1;
         po[3 * pt] = (float)a2; po[3 * pt + 1] = (float)a1; po[3 * pt + 2] = (float)a0;
     }
     // colours: head bytes up to the first dword boundary of the output, then whole dwords, then the tail
@@ -259,15 +305,18 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     const u32 nbytes = 3 * total;
     const u32 head = (u32)((4 - ((uintptr_t)co & 3u)) & 3u);
     const u32 hb = head < nbytes ? head : nbytes;
-    if (threadIdx.x < hb) co[threadIdx.x] = lcol[threadIdx.x];
+    auto stream_byte = [&](u32 q) -> u8 { const u32 r = (q * 43691u) >> 17; return (u8)(lrec[r] >> (8 * (q - 3 * r))); };
+    if (threadIdx.x < hb) co[threadIdx.x] = stream_byte(threadIdx.x);
     const u32 ndw = (nbytes - hb) / 4;
     u32* cw = (u32*)(co + hb);
-    for (u32 k = threadIdx.x; k < ndw; k += 256) {
-        const u8* l = lcol + hb + 4 * k;
-        cw[k] = (u32)l[0] | ((u32)l[1] << 8) | ((u32)l[2] << 16) | ((u32)l[3] << 24);
+    for (u32 d = threadIdx.x; d < ndw; d += 256) {
+        const u32 q = hb + 4 * d;                                   // first stream byte of this dword
+        const u32 r = (q * 43691u) >> 17, ph = q - 3 * r;           // q / 3 exactly (q < 2^16)
+        const unsigned long long two = (unsigned long long)lrec[r] | ((unsigned long long)lrec[r + 1] << 24);
+        cw[d] = (u32)(two >> (8 * ph));
     }
     const u32 tail0 = hb + 4 * ndw;
-    if (threadIdx.x < nbytes - tail0) co[tail0 + threadIdx.x] = lcol[tail0 + threadIdx.x];
+    if (threadIdx.x < nbytes - tail0) co[tail0 + threadIdx.x] = stream_byte(tail0 + threadIdx.x);
 }
 
 int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, int stride, SelParams* p) {
@@ -285,6 +334,30 @@ int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, in
     if (ncolors) memcpy(p->colors, colors, (size_t)3 * ncolors);
     for (int k = 0; k < 32; ++k)
         p->colors32[k] = k < ncolors ? ((u32)colors[3 * k] | ((u32)colors[3 * k + 1] << 8) | ((u32)colors[3 * k + 2] << 16)) : 0xffffffffu;
+    // perfect hash of the colour set: first odd 24-bit multiplier of a fixed sequence under which all (distinct)
+    // colours fall into different entries of the 256-entry table
+    p->hashK = 0;
+    for (int e = 0; e < 256; ++e) p->htab[e] = 1u;
+    if (ncolors > 0) {
+        u32 K = 0x9e3779u;
+        for (int attempt = 0; attempt < (1 << 16) && !p->hashK; ++attempt) {
+            K = (K * 1664525u + 1013904223u) & 0xffffffu;
+            const u32 Ko = K | 1u;
+            u32 tab[256];
+            for (int e = 0; e < 256; ++e) tab[e] = 1u;
+            bool ok = true;
+            for (int k = 0; k < ncolors && ok; ++k) {
+                const u32 c = p->colors32[k];
+                const u32 e = (u32)(((unsigned long long)c * Ko) & 0xffffffffull) >> 24;
+                if (tab[e] == 1u) tab[e] = c << 8;
+                else if (tab[e] != (c << 8)) ok = false;        // a repeated colour is not a collision
+            }
+            if (ok) { p->hashK = Ko; memcpy(p->htab, tab, sizeof(tab)); }
+        }
+    }
+    const Magic g2 = make_magic((u32)(A2 > 0 ? A2 : 1)), g1 = make_magic((u32)(A1 > 0 ? A1 : 1));
+    p->m2 = g2.m; p->s2a = g2.sa; p->s2b = g2.sb;
+    p->m1 = g1.m; p->s1a = g1.sa; p->s1b = g1.sb;
     return PB3D_OK;
 }
 

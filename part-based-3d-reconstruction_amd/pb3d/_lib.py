@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpb3d.so")
+LIB_PATH = os.environ.get("PB3D_LIB_PATH") or os.path.join(_HERE, "libpb3d.so")   # override: A/B builds of the same ABI
 
 u8p = C.POINTER(C.c_uint8)
 i64 = C.c_int64

@@ -552,3 +552,59 @@ def test_reprojection_iou_config3(pb3d_gpu):
         for part in ("full_building", "front_minarets", "back_minarets"):
             assert float(per[part]) == summ[f"Charminar_{view}_part_{part}"], (view, part)
         assert 0.0 < combined <= 1.0
+
+
+@pytest.mark.gpu
+def test_projection_f32_fast_path_adversarial(pb3d_gpu, oracle):
+    """the all-float32 kernels (direct float32 arithmetic, 4 points per lane) against the oracle's generic evaluation:
+    non-integer coordinates over 60 binades incl. float32 denormals, points behind / on the camera plane (Z clamp),
+    quotients that overflow, N not a multiple of 4, and every N in 0..9 (ragged tail of the vector loop)."""
+    rng = np.random.default_rng(77)
+    N = 100003
+    mag = np.exp2(rng.uniform(-30, 30, (N, 3))).astype(np.float32)
+    pts = (mag * rng.choice([-1, 1], (N, 3))).astype(np.float32)
+    pts[:2000] = rng.uniform(-40, 40, (2000, 3)).astype(np.float32)             # a dense cluster that lands in the image
+    pts[2000:2100] = np.float32(1e-42) * rng.integers(-50, 50, (100, 3)).astype(np.float32)   # denormals
+    pts[2100:2200, 2] = np.float32(-30.0)                                        # exactly on the camera plane: Z == 0 -> clamp
+    pts[2200:2300] = rng.uniform(-3e38, 3e38, (100, 3)).astype(np.float32)       # overflow in the FMA chain -> inf/NaN
+    cols = rng.integers(1, 256, (N, 3), dtype=np.uint8)
+    cam = np.array([1.5, -2.25, -30], np.float32); tgt = np.array([0.5, 0.25, 4], np.float32)
+    args = (cam, tgt, 123.456, 63.5, 47.25, 96, 128)
+    with np.errstate(all="ignore"):
+        want = oracle.project_colored_voxels(pts, cols, *args)
+        assert want.any()
+        assert np.array_equal(pb3d_gpu.project_colored_voxels(pts, cols, *args), want)
+        for n in range(10):
+            sub = slice(1000, 1000 + n)
+            assert np.array_equal(pb3d_gpu.project_colored_voxels(pts[sub], cols[sub], *args),
+                                  oracle.project_colored_voxels(pts[sub], cols[sub], *args)), n
+        # the same cloud with a float64 camera goes through the generic kernel: both must agree with the oracle
+        args64 = (cam.astype(np.float64), tgt.astype(np.float64)) + args[2:]
+        assert np.array_equal(pb3d_gpu.project_colored_voxels(pts, cols, *args64), oracle.project_colored_voxels(pts, cols, *args64))
+
+
+@pytest.mark.gpu
+def test_points_colour_sets_hash_probe(pb3d_gpu, oracle):
+    """the stride-1 compaction selects by one perfect-hash probe per voxel: random colour sets of 1..32 entries (with black,
+    repeated entries, colours differing in one bit / one channel, voxel colours that hash like a member but are not one),
+    dims that are powers of two, primes, 1, and longer than a block along the fast axis."""
+    rng = np.random.default_rng(91)
+    for trial, shp in enumerate([(3, 5, 4099), (64, 64, 64), (1, 1, 70000), (31, 1, 257), (7, 129, 33), (2, 4096, 3), (17, 16, 1024)]):
+        ncol = [1, 2, 7, 13, 32, 31, 10][trial]
+        members = rng.integers(0, 256, (ncol, 3), dtype=np.uint8)
+        if trial % 2 == 0:
+            members[0] = 0                                               # black is a member
+        if ncol > 3:
+            members[1] = members[2]                                      # a repeated entry
+            members[3] = members[2] ^ np.array([0, 0, 1], np.uint8)      # one bit away
+        others = np.concatenate([members ^ np.array([1, 0, 0], np.uint8), members[:, ::-1], rng.integers(0, 256, (40, 3), dtype=np.uint8),
+                                 np.zeros((1, 3), np.uint8)])
+        pal = np.concatenate([members, others])
+        grid = pal[rng.integers(0, len(pal), shp)]
+        pc = {f"p{k}": tuple(int(v) for v in members[k]) for k in range(ncol)}
+        gp, gc = pb3d_gpu.get_voxel_points_by_parts(grid, pc, list(pc))
+        op, oc = oracle.get_voxel_points_by_parts(grid, pc, list(pc))
+        assert gp.dtype == np.float32 and np.array_equal(gp, op) and np.array_equal(gc, oc), (shp, ncol)
+        gp, gc, _ = pb3d_gpu.voxel_grid_to_points(grid, stride=1)
+        op, oc, _ = oracle.voxel_grid_to_points(grid, stride=1)
+        assert np.array_equal(gp, op) and np.array_equal(gc, oc), shp

@@ -57,7 +57,17 @@ def main():
         d_in = dev.DeviceBuffer(nvox * 3); d_out = dev.DeviceBuffer(nvox * 3)
         dev.synth_sem(0, S, S, S, 1, d_in)
         report("M1", "carve_voxel_grid_with_masks(sem,binary)", timeit(lambda: dev.carve_mask(d_in, S, S, S, 3, d_mwh, d_out), 20), 6)
+        for parts in (2, 4, 8):      # what one rank of an N-GPU run does (X-slab of S/N planes); ideal = ms(M1) / N
+            ms = timeit(lambda: dev.carve_mask(d_in, S // parts, S, S, 3, d_mwh, d_out), 50)
+            print(json.dumps({"op": "M1/slab", "planes": S // parts, "ms": round(ms, 4), "alg_GB_s": round(6 * nvox / parts / ms / 1e6, 1)}), flush=True)
         d_in.free(); d_out.free()
+    if "A2" in ops or "A6" in ops:      # the two elementwise helpers of the path (not in SURVEY's M list): 4 B/voxel each
+        d_c = dev.DeviceBuffer(nvox * 3); d_o = dev.DeviceBuffer(nvox); d_o2 = dev.DeviceBuffer(nvox)
+        dev.synth_sem(0, S, S, S, 1, d_c)
+        report("A2", "_occupancy(rgb grid)", timeit(lambda: dev.occupancy(d_c, nvox, d_o), 10), 4)
+        dev.carve_mask(d_o, S, S, S, 1, d_mwh, d_o2)
+        report("A6", "apply_colored_mask_to_voxel_grid", timeit(lambda: dev.color_apply(d_o2, S, S, S, d_rgb, d_c), 10), 4)
+        d_c.free(); d_o.free(); d_o2.free()
     d_occ = dev.DeviceBuffer(nvox); d_o1 = dev.DeviceBuffer(nvox); d_tmp = dev.DeviceBuffer(nvox)
     dev.synth_occ(0, S, S, S, 0, d_occ)
     if "M2" in ops:
