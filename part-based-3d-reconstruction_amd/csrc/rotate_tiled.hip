@@ -242,13 +242,18 @@ __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_
 #ifndef ROT90_WAVES
 #define ROT90_WAVES 4
 #endif
-template <int PP>   // planes per pass: PP tiles staged, one barrier pair per PP planes, PP planes of loads in flight
+// DEPTH planes of global loads are in flight per workgroup (register ring, statically indexed by the unrolled slot loop);
+// the LDS tile is double-buffered so a plane costs ONE barrier.  Measured at 1024^3: DEPTH 1 with 4 workgroups/CU 0.51 ms;
+// DEPTH 2 (3 workgroups/CU) 0.55; DEPTH 3-4 (2/CU) 0.63 -- resident waves matter more than bytes in flight.  The memory
+// system's own bound for this traffic (tools/kbench3.hip: 16 KiB tiles of 128-byte rows 1 MiB apart on both sides, no
+// transpose) is 0.455 ms, a linear copy with the same workgroup shape 0.41 ms.
+template <int DEPTH>
 __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
                                                i64 W, i64 H, i64 D, int TY) {
-    __shared__ __attribute__((aligned(16))) u8 tiles[PP][128 * 128];
+    __shared__ __attribute__((aligned(16))) u8 tiles[2][128 * 128];
     const int tid = threadIdx.x;
-    const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;
+    const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;     // (block order: no measurable effect, 4 orders tried)
     const i64 y_beg = (i64)blockIdx.z * TY;
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
     // staging role: local source row lr = (tid >> 3) + 32 j, 16-byte block cb = tid & 7
@@ -267,54 +272,50 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
         const i64 x = x0 + 4 * xg + i;
         vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
     }
-    // Everything a pass needs from global memory is issued together, one pass ahead: the 16-byte source pieces, the
+    // Everything a plane needs from global memory is issued together, DEPTH planes ahead: the 16-byte source pieces, the
     // source-row mask bytes (applied when the data lands, so the two loads are not dependent) and the
     // destination-row mask bytes.
-    u32x4 stg[PP][4];
-    u32 msk[PP];       // byte j: source-row mask of piece j ; bits 28..31: destination-row mask of row i
-    auto load_pass = [&](i64 y0p) {
+    u32x4 stg[DEPTH][4];
+    u32 msk[DEPTH];    // bit j: source-row mask of piece j ; bits 4..7: destination-row mask of row i
+    auto load_plane = [&](u32x4 (&sg)[4], u32& mkout, i64 y) {
+        u32 mk = 0;
 #pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            const i64 y = y0p + pp;
-            u32 mk = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const i64 n0 = rbase + (tid >> 3) + 32 * j;
-                stg[pp][j] = (u32x4)(0u);
-                if (y < y_end && col_ok && n0 >= 0 && n0 < W) {
-                    stg[pp][j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
-                    mk |= (u32)((mask_src ? mask_src[n0 * H + y] : (u8)1) != 0) << j;
-                }
+        for (int j = 0; j < 4; ++j) {
+            const i64 n0 = rbase + (tid >> 3) + 32 * j;
+            sg[j] = (u32x4)(0u);
+            if (y < y_end && col_ok && n0 >= 0 && n0 < W) {
+                sg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
+                mk |= (u32)((mask_src ? mask_src[n0 * H + y] : (u8)1) != 0) << j;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const i64 x = x0 + 4 * xg + i;
-                if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
-            }
-            msk[pp] = mk;
         }
-    };
-    load_pass(y_beg);
-    for (i64 y0p = y_beg; y0p < y_end; y0p += PP) {
-        u32 mkc[PP];
 #pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            mkc[pp] = msk[pp];
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
+        }
+        mkout = mk;
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) load_plane(stg[s], msk[s], y_beg + s);
+    int buf = 0;
+    for (i64 y0p = y_beg; y0p < y_end; y0p += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const i64 y = y0p + s;
+            if (y >= y_end) break;                       // uniform
+            u8* tile = tiles[buf];
+            buf ^= 1;
+            const u32 mkc = msk[s];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int lr = (tid >> 3) + 32 * j;
-                *(u32x4*)(tiles[pp] + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ((mkc[pp] >> j) & 1u) ? stg[pp][j] : (u32x4)(0u);
+                *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ((mkc >> j) & 1u) ? stg[s][j] : (u32x4)(0u);
             }
-        }
-        __syncthreads();
-        if (y0p + PP < y_end) load_pass(y0p + PP);
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            const i64 y = y0p + pp;
-            if (y >= y_end) break;
+            __syncthreads();      // the only barrier of the plane: the other tile buffer was last read before the previous one
+            load_plane(stg[s], msk[s], y + DEPTH);
             u32 d[16];
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tiles[pp] + rd_off + rr * 128);
+            for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
             u32 o[4][4];  // o[i][w]: output x = 4 xg + i, bytes q = 4w .. 4w+3 ; byte q <- d[15 - q].byte[i]
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 const i64 x = x0 + 4 * xg + i;
                 if (x >= W || zo >= D) continue;
                 u32x4 r = (u32x4)(0u);
-                if ((mkc[pp] >> (4 + i)) & 1u) {
+                if ((mkc >> (4 + i)) & 1u) {
                     r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
                     if (vb[i] != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
                         u32 mw[4];
@@ -347,7 +348,6 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 __builtin_nontemporal_store(r, (u32x4*)(out + (x * H + y) * D + zo));
             }
         }
-        __syncthreads();
     }
 }
 
@@ -573,10 +573,10 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
         while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
         dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
-#ifndef PB3D_ROT90_PP
-#define PB3D_ROT90_PP 1
+#ifndef PB3D_ROT90_DEPTH
+#define PB3D_ROT90_DEPTH 1
 #endif
-        hipLaunchKernelGGL(k_rot90<PB3D_ROT90_PP>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
+        hipLaunchKernelGGL(k_rot90<PB3D_ROT90_DEPTH>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
                            pm.c0, pm.c2, W, H, D, TY);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
