@@ -14,7 +14,7 @@ typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-#define PB3D_NSCRATCH 16
+#define PB3D_NSCRATCH 20
 
 struct pb3d_event {
     hipEvent_t ev;

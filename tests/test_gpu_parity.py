@@ -504,7 +504,9 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
     """grids above 2^21 voxels take the LDS-tiled lookup-table kernel for generic angles; 0/1 data stays on the table
     path, 0..255 data must raise the device flag and be redone by the arithmetic kernel -- both bit-exact."""
     rng = np.random.default_rng(43)
-    for (W, H, D) in [(160, 90, 160), (200, 60, 180), (131, 128, 130)]:
+    # (160,90,160) / (176,64,192): 32-plane bit-sliced kernel (ragged / whole passes); (400,20,272): 8-plane aligned kernel;
+    # (200,60,180) / (131,128,130): 8-plane kernel with byte-wise edges
+    for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130)]:
         m = rng.random((H, W)) < 0.9
         g_bin = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         g_full = rng.integers(0, 256, (W, H, D), dtype=np.uint8)
