@@ -93,6 +93,7 @@ static inline unsigned pb3d_stream_blocks(const pb3d_ctx* ctx, i64 work_items, i
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
                                const double off[3], const u8* d_mask_wh, u8* d_out);
 bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D);
+bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b);
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
                             const u8* d_mask_src, const u8* d_mask_dst, u8* d_out);
 int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,

@@ -363,6 +363,7 @@ constexpr int WCELLS = LT * LT / WTHREADS;        // 16 cells per thread: row xl
 constexpr int WTPR = LT / WCELLS;                 // threads per tile row
 constexpr int WMAXU = (WROWS * (WPITCH / 16) + WTHREADS - 1) / WTHREADS;
 
+template <bool RAGGED>      // false: D % 16 == 0, no piece or run straddles a row end (byte-wise paths compiled out)
 __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
                                                               const CellRec* __restrict__ cells, i64 W, i64 H, i64 D, int TY, int ntz,
                                                               int ntiles, int* __restrict__ big_flag) {
@@ -370,6 +371,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
     __shared__ int bb[4];
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x4 u32x4_a1 __attribute__((aligned(1)));     // any byte alignment (rows of odd-sized grids)
+    typedef u32x2 u32x2_a1 __attribute__((aligned(1)));
     const int tid = threadIdx.x;
     const int chunk = (ntiles + 7) >> 3;
     const int slot = (int)(blockIdx.x >> 3);
@@ -382,17 +385,23 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
     __syncthreads();
     const int zl = (tid % WTPR) * WCELLS, xl0 = tid / WTPR;
     const i64 x = x0 + xl0;
-    const bool row_ok = x < W && z0 + zl < D;        // D % 16 == 0: a 16-run is inside or outside as a whole
+    const bool row_ok = x < W && z0 + zl < D;        // the run may be ragged (z0 + zl + WCELLS > D): cells past D are void
     u32 src[WCELLS], lut[WCELLS];
     int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
 #pragma unroll
     for (int c = 0; c < WCELLS; ++c) { src[c] = 0xffffffffu; lut[c] = 0; }
     if (row_ok) {
-        const u32x4* cp = (const u32x4*)(cells + x * D + z0 + zl);          // WCELLS records, 16-byte aligned
+        typedef u32x4 u32x4_u __attribute__((aligned(8)));
+        const u32x4_u* cp = (const u32x4_u*)(cells + x * D + z0 + zl);      // WCELLS records (the table is padded by WCELLS)
 #pragma unroll
         for (int k = 0; k < WCELLS / 2; ++k) {
             const u32x4 v = cp[k];
             src[2 * k] = v.x; lut[2 * k] = v.y; src[2 * k + 1] = v.z; lut[2 * k + 1] = v.w;
+        }
+        if (RAGGED && z0 + zl + WCELLS > D) {
+#pragma unroll
+            for (int c = 0; c < WCELLS; ++c)
+                if (z0 + zl + c >= D) { src[c] = 0xffffffffu; lut[c] = 0; }
         }
 #pragma unroll
         for (int c = 0; c < WCELLS; ++c) {
@@ -500,10 +509,21 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
                 u32x4 d[16];
+                // the ragged unit at a row's end may be read whole while it stays inside the volume (the bytes past the row are
+                // only ever zero-weight taps); byte-wise only at the very end of the buffer
+                const bool whole = !RAGGED || (i64)bz0 + 16 * cu + 15 < D || (i64)voff + (yg + 16 * gg + 15) * D + 16 <= W * H * D;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const u8* pb = in + (yg + 16 * gg + q) * D;      // uniform
-                    d[q] = (16 * gg + q < np) ? *(const u32x4*)(pb + voff) : (u32x4)(0u);
+                    d[q] = (u32x4)(0u);
+                    if (16 * gg + q < np) {
+                        if (whole) d[q] = *(const u32x4_a1*)(pb + voff);
+                        else {
+                            u32 t4[4] = {0, 0, 0, 0};
+                            for (int b = 0; (i64)bz0 + 16 * cu + b < D; ++b) t4[b >> 2] |= (u32)pb[voff + b] << (8 * (b & 3));
+                            d[q].x = t4[0]; d[q].y = t4[1]; d[q].z = t4[2]; d[q].w = t4[3];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -550,8 +570,15 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
 #pragma unroll
                 for (int i = 0; i < WCELLS / 4; ++i) rr[i] = (G[i][q >> 3] >> (q & 7)) & keep;
                 u8* pb = out + (yg + q) * D;                          // uniform
-                if (WCELLS == 16) { u32x4 r; r.x = rr[0]; r.y = rr[1]; r.z = rr[2 % (WCELLS / 4)]; r.w = rr[3 % (WCELLS / 4)]; *(u32x4*)(pb + ooff) = r; }
-                else { u32x2 r; r.x = rr[0]; r.y = rr[1]; *(u32x2*)(pb + ooff) = r; }
+                if (!RAGGED || z0 + zl + WCELLS <= D) {
+                    if (WCELLS == 16) { u32x4 r; r.x = rr[0]; r.y = rr[1]; r.z = rr[2 % (WCELLS / 4)]; r.w = rr[3 % (WCELLS / 4)]; *(u32x4_a1*)(pb + ooff) = r; }
+                    else { u32x2 r; r.x = rr[0]; r.y = rr[1]; *(u32x2_a1*)(pb + ooff) = r; }
+                } else {
+                    typedef u32 u32_a1 __attribute__((aligned(1)));
+                    const int k = (int)(D - z0 - zl);                  // 1..15 bytes: whole dwords, then bytes
+                    for (int j = 0; j < (k >> 2); ++j) *(u32_a1*)(pb + ooff + 4 * j) = rr[j];
+                    for (int b = k & ~3; b < k; ++b) pb[ooff + b] = (u8)(rr[b >> 2] >> (8 * (b & 3)));
+                }
             }
         }
         __syncthreads();
@@ -587,17 +614,21 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
         while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
         dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
         PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
-        if (D % 16 == 0 && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u) == 0 && H >= 32 && W * H * D < (1ll << 32)) {
+        if (H >= 32 && W * H * D < (1ll << 32) - 64) {
             void* cells;
-            PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D) * sizeof(CellRec), &cells));
+            PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + WCELLS) * sizeof(CellRec), &cells));
             hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells);
             PB3D_CHECK_LAUNCH();
             int TYW = 64;        // multiples of 32 planes per workgroup (measured at 1024^3: 32/64 planes 0.76 ms, 128: 0.79, 256: 0.88)
             while (TYW > 32 && tiles * ((H + TYW - 1) / TYW) < (i64)ctx->cus * 4) TYW >>= 1;
             const i64 nblk = 8 * ((tiles + 7) / 8) * ((H + TYW - 1) / TYW);
             PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
-            hipLaunchKernelGGL(k_rotate_bits32, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh, (const CellRec*)cells,
-                               W, H, D, TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
+            if (D % 16 == 0)
+                hipLaunchKernelGGL(k_rotate_bits32<false>, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh,
+                                   (const CellRec*)cells, W, H, D, TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
+            else
+                hipLaunchKernelGGL(k_rotate_bits32<true>, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh,
+                                   (const CellRec*)cells, W, H, D, TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
         } else if (D % 16 == 0 && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u) == 0)
             hipLaunchKernelGGL(k_rotate_bits<true>, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
         else
@@ -628,7 +659,7 @@ int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     if (W * H * D == 0) return PB3D_OK;
     PB3D_REQUIRE(d_occ && d_out && d_occ != d_out, "pb3d_rotate_carve: null or aliased buffer");
     const bool row1 = M[3] == 0.0 && M[4] == 1.0 && M[5] == 0.0 && M[1] == 0.0 && M[7] == 0.0 && off[1] == 0.0;
-    if (row1 && pb3d_is_perm_step(M, off, W, D) && D % 4 == 0 && (((uintptr_t)d_occ | (uintptr_t)d_out) & 3u) == 0)
+    if (row1 && pb3d_perm_step_ok(M, off, W, D, d_occ, d_out))
         return pb3d_launch_rotate_perm(ctx, d_occ, W, H, D, M, off, nullptr, d_mask_wh, d_out);
     return pb3d_launch_rotate_generic(ctx, d_occ, W, H, D, M, off, d_mask_wh, d_out);
 }
@@ -657,8 +688,7 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     PB3D_TRY(pb3d_rotinv(angle_interval, M1));
     PB3D_TRY(pb3d_offset(M1, shape, off1));
     // A permutation-like second step (90 degrees, W + D even) takes the 0-degree carve as its source mask.
-    const bool fuse_first = pb3d_is_perm_step(M1, off1, W, D) && D % 4 == 0 &&
-                            (((uintptr_t)d_occ | (uintptr_t)d_out | (uintptr_t)d_tmp) & 3u) == 0;
+    const bool fuse_first = pb3d_perm_step_ok(M1, off1, W, D, d_occ, d_out) && pb3d_perm_step_ok(M1, off1, W, D, d_occ, d_tmp);
     const int nlaunch = fuse_first ? nsteps - 1 : nsteps;
     const u8* src = d_occ;
     int li = 0;
@@ -670,7 +700,7 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
             double M[9], off[3];
             PB3D_TRY(pb3d_rotinv(s * angle_interval, M));
             PB3D_TRY(pb3d_offset(M, shape, off));
-            if (pb3d_is_perm_step(M, off, W, D) && D % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3u) == 0)
+            if (pb3d_perm_step_ok(M, off, W, D, src, dst))
                 PB3D_TRY(pb3d_launch_rotate_perm(ctx, src, W, H, D, M, off, (fuse_first && s == 1) ? d_mask_wh : nullptr, d_mask_wh, dst));
             else
                 PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst));

@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256) void k_rot_valid(RotParams p, i64 W, i64 D, in
 }
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));     // 16-byte access at any byte alignment (rows of odd-sized grids)
+typedef u32 u32_u __attribute__((aligned(1)));
 
 // ------------------------------------------------------------------------------------------------
 // K4: global_carve(binary, rgb, 90) fused: occ[x,y,z] = bm[x,y] && valid(x,z) && bm[c0 - z, y],
@@ -230,7 +232,10 @@ __global__ __launch_bounds__(256) void k_global_carve90b(const u8* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2' fast form for the 90-degree map n0 = c0 - z, n2 = x + c2 (c2 % 16 == 0, D % 16 == 0):
+// K2' fast form for the 90-degree map n0 = c0 - z, n2 = x + c2.  Any W, H, D and any pointer alignment: gfx950 serves
+// 16-byte global accesses at arbitrary byte addresses at full speed (tools/kbench4.hip), so rows of odd-sized grids
+// (355, 437, 123 ... voxels, the reference's real shapes) use the same 16-byte pieces; only the ragged piece at a row's
+// end is moved byte-wise.
 // 128 x 128 byte tiles, 16-byte global loads and stores (full 128-byte lines on both sides), the
 // transpose done in registers: the source tile sits row-major in LDS (16-byte blocks XOR-swizzled by
 // the row group so that the column reads are bank-conflict free), each thread reads a 16-row x
@@ -247,7 +252,9 @@ __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_
 // DEPTH 2 (3 workgroups/CU) 0.55; DEPTH 3-4 (2/CU) 0.63 -- resident waves matter more than bytes in flight.  The memory
 // system's own bound for this traffic (tools/kbench3.hip: 16 KiB tiles of 128-byte rows 1 MiB apart on both sides, no
 // transpose) is 0.455 ms, a linear copy with the same workgroup shape 0.41 ms.
-template <int DEPTH>
+// RAGGED = false: D % 16 == 0 and c2 % 16 == 0, every piece is whole and the byte-wise paths are compiled out (they cost
+// 25 % at 1024^3 when merely present)
+template <int DEPTH, bool RAGGED>
 __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
                                                i64 W, i64 H, i64 D, int TY) {
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
     const int cb = tid & 7;
     const i64 rbase = (i64)c0 - (z0 + 127);             // source row of local row 0
     const i64 scol = x0 + c2 + 16 * cb;                 // source column of this thread's block
-    const bool col_ok = scol >= 0 && scol + 15 < D;
+    const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
     // output role: z-run zg = tid & 7 (16 z), x-group xg = tid >> 3 (4 x)
     const int zg = tid & 7, xg = tid >> 3;
     const int g = 7 - zg;                               // row group holding this thread's 16 source rows
@@ -283,8 +290,17 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
             sg[j] = (u32x4)(0u);
-            if (y < y_end && col_ok && n0 >= 0 && n0 < W) {
-                sg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
+            if (y < y_end && (RAGGED ? cmode != 0 : cmode == 2) && n0 >= 0 && n0 < W) {
+                const u8* sp = in + (n0 * H + y) * D + scol;
+                // a ragged piece may be read whole as long as it stays inside the volume: the bytes beyond the row belong to
+                // the neighbouring row and are dropped by the validity bits (their source column is outside [0, D))
+                if (!RAGGED || cmode == 2 || (sp >= in && sp + 16 <= in + W * H * D)) sg[j] = __builtin_nontemporal_load((const u32x4_u*)sp);
+                else {
+                    u32 t4[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; ++b)
+                        if (scol + b >= 0 && scol + b < D) t4[b >> 2] |= (u32)sp[b] << (8 * (b & 3));
+                    sg[j].x = t4[0]; sg[j].y = t4[1]; sg[j].z = t4[2]; sg[j].w = t4[3];
+                }
                 mk |= (u32)((mask_src ? mask_src[n0 * H + y] : (u8)1) != 0) << j;
             }
         }
@@ -345,7 +361,14 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                         r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
                     }
                 }
-                __builtin_nontemporal_store(r, (u32x4*)(out + (x * H + y) * D + zo));
+                u8* op = out + (x * H + y) * D + zo;
+                if (!RAGGED || zo + 15 < D) __builtin_nontemporal_store(r, (u32x4_u*)op);
+                else {
+                    const u32 t4[4] = {r.x, r.y, r.z, r.w};
+                    const int k = (int)(D - zo);                       // 1..15 bytes: whole dwords, then bytes
+                    for (int j = 0; j < (k >> 2); ++j) *(u32_u*)(op + 4 * j) = t4[j];
+                    for (int b = k & ~3; b < k; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+                }
             }
         }
     }
@@ -521,6 +544,14 @@ __global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_
 // true when the (x,z) part of (M, off) is a signed permutation up to 2^-40 with an offset within
 // 2^-20 of an integer: every coordinate of every voxel (< 2^20 per axis) is then within 2^-18 of an
 // integer and the step is an exact byte permutation (see the header of this file).
+// a permutation-like step that pb3d_launch_rotate_perm can run on these buffers: the 90-degree map has no alignment or
+// size condition (k_rot90); the other signed permutations (180, 270 degrees) use the dword kernel k_rotate_perm
+bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b) {
+    if (!pb3d_is_perm_step(M, off, W, D)) return false;
+    const bool rot90 = nearbyint(M[0]) == 0 && nearbyint(M[2]) == -1 && nearbyint(M[6]) == 1 && nearbyint(M[8]) == 0;
+    return rot90 || (D % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) & 3u) == 0);
+}
+
 bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D) {
     if (W >= (1ll << 20) || D >= (1ll << 20)) return false;
     const int idx[4] = {0, 2, 6, 8};
@@ -562,11 +593,11 @@ static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u3
 
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
                             const u8* d_mask_src, const u8* d_mask_dst, u8* d_out) {
-    PB3D_REQUIRE(D % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 3u) == 0, "pb3d_rotate_perm: needs D %% 4 == 0");
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     const PermMap pm = perm_map(M, off);
     const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
-    if (rot90 && D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0 && W <= 65535 && H <= 65535) {
+    PB3D_REQUIRE(rot90 || (D % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 3u) == 0), "pb3d_rotate_perm: needs D %% 4 == 0");
+    if (rot90 && W <= 65535 * 128 && H <= 65535) {
         u32* bits; int nw;
         PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
         int TY = 32;
@@ -576,8 +607,12 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
 #ifndef PB3D_ROT90_DEPTH
 #define PB3D_ROT90_DEPTH 1
 #endif
-        hipLaunchKernelGGL(k_rot90<PB3D_ROT90_DEPTH>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
-                           pm.c0, pm.c2, W, H, D, TY);
+        if (D % 16 == 0 && pm.c2 % 16 == 0)
+            hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY);
+        else
+            hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }

@@ -284,11 +284,14 @@ def test_full_size_carve_properties(pb3d_gpu):
 
 
 def test_process90_tiled_permutation_sizes(pb3d_gpu, oracle):
-    """the LDS-tiled 90-degree path (W + D even, D % 4 == 0) on sizes that are not tile multiples, next to
-    shapes that must fall back to the generic kernel (W + D odd -> half-integer coordinates; D % 4 != 0)."""
+    """the LDS-tiled 90-degree path (W + D even; any D, any row alignment: whole 16-byte pieces at arbitrary byte addresses,
+    ragged pieces at row ends, W != D so the column offset c2 is non-zero and of either sign) on sizes that are not tile
+    multiples, next to shapes that must fall back to the generic kernel (W + D odd -> half-integer coordinates)."""
     rng = np.random.default_rng(29)
     for (W, H, D) in [(100, 7, 100), (68, 5, 132), (132, 3, 68), (64, 2, 64), (4, 3, 4), (260, 4, 260), (200, 2, 72),
-                      (130, 3, 62), (63, 4, 64), (65, 2, 65), (128, 3, 128), (256, 2, 256), (192, 5, 192)]:
+                      (130, 3, 62), (63, 4, 64), (65, 2, 65), (128, 3, 128), (256, 2, 256), (192, 5, 192),
+                      (355, 6, 355), (123, 9, 123), (37, 5, 51), (51, 5, 37), (131, 7, 129), (1, 3, 1), (17, 4, 1), (1, 4, 17),
+                      (150, 3, 200), (437, 2, 437), (15, 11, 15), (16, 3, 18)]:
         for kind in ("bin", "full"):
             g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "bin" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
             m = rng.random((H, W)) < 0.85
@@ -504,9 +507,10 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
     """grids above 2^21 voxels take the LDS-tiled lookup-table kernel for generic angles; 0/1 data stays on the table
     path, 0..255 data must raise the device flag and be redone by the arithmetic kernel -- both bit-exact."""
     rng = np.random.default_rng(43)
-    # (160,90,160) / (176,64,192): 32-plane bit-sliced kernel (ragged / whole passes); (400,20,272): 8-plane aligned kernel;
-    # (200,60,180) / (131,128,130): 8-plane kernel with byte-wise edges
-    for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130)]:
+    # (160,90,160) / (176,64,192): 32-plane bit-sliced kernel (ragged / whole passes); (200,60,180) / (131,128,130) /
+    # (133,121,129): the same kernel with rows at arbitrary byte alignment and ragged row ends; (400,20,272) / (300,20,357):
+    # fewer than 32 planes -> 8-plane kernel, aligned and byte-wise forms
+    for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130), (133, 121, 129), (300, 20, 357)]:
         m = rng.random((H, W)) < 0.9
         g_bin = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         g_full = rng.integers(0, 256, (W, H, D), dtype=np.uint8)

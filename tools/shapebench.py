@@ -1,0 +1,44 @@
+"""Device-resident timing of the 90-degree ops on the reference's real grid shapes (odd / unaligned dims).
+python tools/shapebench.py  -> one JSON line per (shape, op)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "part-based-3d-reconstruction_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import pb3d  # noqa: E402
+from pb3d import device as dev  # noqa: E402
+
+
+def timeit(fn, reps=5):
+    fn(); dev.sync()
+    e0, e1 = dev.Event(), dev.Event()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); dev.sync()
+    return e1.elapsed_ms_since(e0) / reps
+
+
+def main():
+    rng = np.random.default_rng(5)
+    shapes = [(128, 123, 128), (512, 278, 512), (355, 512, 355), (512, 512, 512), (437, 512, 437), (500, 400, 500)]
+    for (W, H, D) in shapes:
+        nvox = W * H * D
+        m_hw = (rng.random((H, W)) < 0.8)
+        rgb = rng.integers(1, 255, (H, W, 3), dtype=np.uint8)
+        d_mwh = dev.from_numpy(np.ascontiguousarray(m_hw.T).view(np.uint8))
+        d_bhw = dev.from_numpy(np.ascontiguousarray(m_hw).view(np.uint8))
+        d_rgb = dev.from_numpy(rgb)
+        occ = (rng.random((W, H, D)) < 0.6).astype(np.uint8)
+        d_occ = dev.from_numpy(occ); d_o = dev.DeviceBuffer(nvox); d_t = dev.DeviceBuffer(nvox); d_col = dev.DeviceBuffer(nvox * 3)
+        rows = {"process_voxel_grid(occ,90)": (timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t)), 2),
+                "process_voxel_grid(occ,45) per step": (timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 45, d_o, d_t)) / 2, 2),
+                "global_carve(90)": (timeit(lambda: dev.global_carve(d_bhw, d_rgb, H, W, 90, d_col)), 3)}
+        for name, (ms, bpv) in rows.items():
+            print(json.dumps({"shape": [W, H, D], "op": name, "ms": round(ms, 4), "Mvoxel_s": round(nvox / ms / 1e3, 1),
+                              "alg_GB_s": round(bpv * nvox / ms / 1e6, 1)}), flush=True)
+        for b in (d_mwh, d_bhw, d_rgb, d_occ, d_o, d_t, d_col):
+            b.free()
+
+
+if __name__ == "__main__":
+    main()
