@@ -8,9 +8,10 @@
 namespace {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));     // 16-byte access at any byte alignment (odd-sized grids, buffer views)
 
-__device__ __forceinline__ u32x4 ld_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_nt(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ u32x4 ld_nt(const u32x4_u* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_nt(u32x4_u* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
 // RGB side of the 16-voxels-per-lane kernels: a lane owns 48 contiguous bytes, so every 128-byte line is touched by three
 // instructions of the wave.  Nontemporal hints make the line leave the L1 between them (measured 1.4x slower on the
 // point sweep of project.hip), so these accesses stay plain.
@@ -23,7 +24,7 @@ __device__ __forceinline__ void st_s(u32x4* p, u32x4 v) { if (PB3D_STRIDED_NT) _
 // RGB stores of those kernels: the wave's 64 groups form 3 KiB contiguous in the output (vector index 3 * gw0 ...), but a lane
 // holds vectors 3*lane .. 3*lane+2 of it.  Route them through a wave-private LDS window (192 vectors) so that every store
 // instruction writes 1 KiB contiguous (whole 128-byte lines) instead of 16 bytes every 48.  Called by all 64 lanes.
-__device__ __forceinline__ void store48_wave(u32x4* __restrict__ out, i64 gw0, i64 ngroups, const u32x4 r[3], u32x4* lds_w) {
+__device__ __forceinline__ void store48_wave(u32x4_u* __restrict__ out, i64 gw0, i64 ngroups, const u32x4 r[3], u32x4* lds_w) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 3; ++k) lds_w[3 * lane + k] = r[k];
@@ -35,7 +36,7 @@ __device__ __forceinline__ void store48_wave(u32x4* __restrict__ out, i64 gw0, i
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int idx = lane + 64 * k;
-        if (idx < nvec) st_nt(out + 3 * gw0 + idx, lds_w[idx]);
+        if (idx < nvec) __builtin_nontemporal_store(lds_w[idx], out + 3 * gw0 + idx);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -113,6 +114,82 @@ __global__ __launch_bounds__(256) void k_carve_bytes(const u8* __restrict__ in, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1 for any column size col = D*C >= 16 bytes and any buffer alignment (odd-sized grids: 355, 437, 123 ... voxels).  The
+// volume is swept as the same flat stream of 16-byte pieces in 12 KiB tiles; a piece lies in one column or straddles
+// two, in which case its bytes are masked on both sides of the boundary.  Column of a piece: one exact multiply-high
+// division of its tile-relative byte offset.  Dropped pieces are never read.
+// ------------------------------------------------------------------------------------------------
+struct Magic32 { u32 m; int sa, sb; };
+inline Magic32 make_magic32(u32 d) {     // exact u32 division, 1 <= d < 2^31 (Granlund-Montgomery round-up form)
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    Magic32 g;
+    g.m = (u32)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    g.sa = L < 1 ? L : 1;
+    g.sb = L > 1 ? L - 1 : 0;
+    return g;
+}
+__device__ __forceinline__ u32 magic_div32(u32 n, Magic32 g) {
+    const u32 t = __umulhi(g.m, n);
+    return (t + ((n - t) >> g.sa)) >> g.sb;
+}
+// dword j of a 16-byte mask whose bytes below position b (0..16) are 0xff
+__device__ __forceinline__ u32 below_mask(int b, int j) {
+    const int n = b - 4 * j;
+    return n >= 4 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << (8 * n)) - 1u));
+}
+
+__global__ __launch_bounds__(kTileThreads) void k_carve_flat(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask,
+                                                             i64 nbytes, i64 ncols, u32 col, Magic32 mg) {
+    __shared__ u8 smask[kTileVec + 4];
+    const i64 b_begin = (i64)blockIdx.x * (kTileVec * 16);
+    const i64 first_col = b_begin / col;                        // block-uniform
+    const u32 rem0 = (u32)(b_begin - first_col * col);
+    const i64 left = nbytes - b_begin;
+    const u32 n_here = left < kTileVec * 16 ? (u32)left : (u32)(kTileVec * 16);       // bytes of this tile
+    const u32 ncol_here = magic_div32(rem0 + n_here - 1, mg) + 1;
+    for (u32 c = threadIdx.x; c < ncol_here; c += kTileThreads) smask[c] = first_col + c < ncols ? mask[first_col + c] : (u8)0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const u32 bo = 16u * (threadIdx.x + kTileThreads * u);   // byte offset of this lane's piece in the tile
+        const bool live = bo < n_here;
+        bool k0 = false, k1 = false, keep = false;
+        int bnd = 16;                                            // bytes of the piece that belong to its first column
+        if (live) {
+            const u32 q = rem0 + bo, c0 = magic_div32(q, mg);
+            const u32 to_end = col - (q - c0 * col);             // >= 1
+            k0 = smask[c0] != 0;
+            if (to_end < 16 && bo + to_end < n_here) { bnd = (int)to_end; k1 = smask[c0 + 1] != 0; }
+            keep = k0 || k1;
+        }
+        if (!live) continue;
+        const u8* sp = in + b_begin + bo;
+        u8* dp = out + b_begin + bo;
+        const bool whole = bo + 16 <= n_here;                    // else: the last piece of the volume, byte-wise
+        u32x4 x = (u32x4)(0u);
+        if (keep) {                                              // dropped pieces are never read
+            if (whole) x = __builtin_nontemporal_load((const u32x4_u*)sp);
+            else {
+                u32 t4[4] = {0, 0, 0, 0};
+                for (u32 b = 0; bo + b < n_here; ++b) t4[b >> 2] |= (u32)sp[b] << (8 * (b & 3));
+                x.x = t4[0]; x.y = t4[1]; x.z = t4[2]; x.w = t4[3];
+            }
+            if (bnd < 16 || !k0) {                               // mixed piece: bytes below bnd follow k0, the rest k1
+                const u32 a = k0 ? 0xffffffffu : 0u, b2 = k1 ? 0xffffffffu : 0u;
+                const u32 m0 = below_mask(bnd, 0), m1 = below_mask(bnd, 1), m2 = below_mask(bnd, 2), m3 = below_mask(bnd, 3);
+                x.x &= (m0 & a) | (~m0 & b2); x.y &= (m1 & a) | (~m1 & b2); x.z &= (m2 & a) | (~m2 & b2); x.w &= (m3 & a) | (~m3 & b2);
+            }
+        }
+        if (whole) __builtin_nontemporal_store(x, (u32x4_u*)dp);
+        else {
+            const u32 t4[4] = {x.x, x.y, x.z, x.w};
+            for (u32 b = 0; bo + b < n_here; ++b) dp[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
 // The mirror image for loads: the wave reads its 3 KiB with three contiguous 1 KiB instructions into the LDS window and
 // every lane then picks up its own 48 bytes.  Called by all 64 lanes; lanes past the end get zeros.
 __device__ __forceinline__ void load48_wave(const u32x4* __restrict__ in, i64 gw0, i64 ngroups, u32x4 r[3], u32x4* lds_w) {
@@ -181,35 +258,49 @@ __device__ __forceinline__ void expand16(const u32 keep16, const u32 r, const u3
     }
 }
 
-__global__ __launch_bounds__(256) void k_color_apply16(const u32x4* __restrict__ carved, const u8* __restrict__ rgb_hw3,
-                                                       u32x4* __restrict__ out, i64 W, i64 H, i64 D16, i64 ngroups) {
+// FLAT = false: D % 16 == 0, a group of 16 voxels lies in one column.  FLAT = true: any D >= 16 -- groups are cut from the
+// flat voxel stream and may straddle two columns (two pixel colours, split at voxel `bnd`).
+template <bool FLAT>
+__global__ __launch_bounds__(256) void k_color_apply16(const u8* __restrict__ carved, const u8* __restrict__ rgb_hw3,
+                                                       u8* __restrict__ out, i64 W, i64 H, i64 D, i64 ngroups) {
     __shared__ u32x4 stage[4][192];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (i64 gw0 = (i64)blockIdx.x * blockDim.x + 64 * wv; gw0 < ngroups; gw0 += (i64)gridDim.x * blockDim.x) {   // wave-uniform
         const i64 g = gw0 + lane;
         u32x4 r[3] = {(u32x4)(0u), (u32x4)(0u), (u32x4)(0u)};
         if (g < ngroups) {
-            const i64 xy = g / D16;
+            const i64 xy = (16 * g) / D;
             const i64 x = xy / H, y = xy - x * H;
             const u8* px = rgb_hw3 + (y * W + x) * 3;
-            const u32x4 cv = ld_nt(carved + g);
+            const u32x4 cv = ld_nt((const u32x4_u*)(carved + 16 * g));
             const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
             u32 keep16 = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) keep16 |= (byte_of(cw, i) == 1u ? 1u : 0u) << i;
             u32 w[12];
-            expand16(keep16, px[0], px[1], px[2], w);
+            const i64 bnd = FLAT ? (xy + 1) * D - 16 * g : 16;     // voxels of the group that belong to column xy
+            if (!FLAT || bnd >= 16) expand16(keep16, px[0], px[1], px[2], w);
+            else {
+                const i64 xy1 = xy + 1, x1 = xy1 / H, y1 = xy1 - x1 * H;
+                const u8* qx = rgb_hw3 + (y1 * W + x1) * 3;
+                const u32 lo = (1u << bnd) - 1u;
+                u32 w2[12];
+                expand16(keep16 & lo, px[0], px[1], px[2], w);
+                expand16(keep16 & ~lo, qx[0], qx[1], qx[2], w2);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) w[k] |= w2[k];
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) { r[k].x = w[4 * k]; r[k].y = w[4 * k + 1]; r[k].z = w[4 * k + 2]; r[k].w = w[4 * k + 3]; }
         }
-        store48_wave(out, gw0, ngroups, r, stage[wv]);
+        store48_wave((u32x4_u*)out, gw0, ngroups, r, stage[wv]);
     }
 }
 
 __global__ __launch_bounds__(256) void k_color_apply_generic(const u8* __restrict__ carved, const u8* __restrict__ rgb_hw3,
-                                                             u8* __restrict__ out, i64 W, i64 H, i64 D) {
+                                                             u8* __restrict__ out, i64 W, i64 H, i64 D, i64 v_first) {
     const i64 nvox = W * H * D;
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+    for (i64 v = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
         const i64 xy = v / D;
         const i64 x = xy / H, y = xy - x * H;
         const u8* px = rgb_hw3 + (y * W + x) * 3;
@@ -353,6 +444,10 @@ int pb3d_carve_mask_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t W, int64_t
         const unsigned blocks = (unsigned)((nvec + kTileVec - 1) / kTileVec);
         hipLaunchKernelGGL(k_carve_tiles, dim3(blocks), dim3(kTileThreads), 0, ctx->stream, (const u32x4*)d_grid,
                            (u32x4*)d_out, d_mask_wh, nvec, ncols, vpc, magic);
+    } else if (col >= 16 && col < (1ll << 31) - kTileVec * 16 && (nbytes + kTileVec * 16 - 1) / (kTileVec * 16) < (1ll << 31)) {
+        const unsigned blocks = (unsigned)((nbytes + kTileVec * 16 - 1) / (kTileVec * 16));
+        hipLaunchKernelGGL(k_carve_flat, dim3(blocks), dim3(kTileThreads), 0, ctx->stream, d_grid, d_out, d_mask_wh, nbytes, ncols, (u32)col,
+                           make_magic32((u32)col));
     } else {
         const unsigned blocks = pb3d_stream_blocks(ctx, (nbytes + 15) / 16, 256, 8);
         hipLaunchKernelGGL(k_carve_bytes, dim3(blocks), dim3(256), 0, ctx->stream, d_grid, d_out, d_mask_wh, nbytes, col);
@@ -387,14 +482,19 @@ int pb3d_color_apply_dev(pb3d_ctx* ctx, const uint8_t* d_carved, int64_t W, int6
     const i64 nvox = W * H * D;
     if (nvox == 0) return PB3D_OK;
     PB3D_REQUIRE(d_carved && d_rgb_hw3 && d_out, "pb3d_color_apply: null buffer");
-    if (D % 16 == 0 && aligned16(d_carved) && aligned16(d_out)) {
-        const i64 ngroups = nvox / 16;
-        hipLaunchKernelGGL(k_color_apply16, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 8)), dim3(256), 0, ctx->stream,
-                           (const u32x4*)d_carved, d_rgb_hw3, (u32x4*)d_out, W, H, D / 16, ngroups);
-    } else {
-        hipLaunchKernelGGL(k_color_apply_generic, dim3(pb3d_stream_blocks(ctx, nvox, 256, 8)), dim3(256), 0, ctx->stream,
-                           d_carved, d_rgb_hw3, d_out, W, H, D);
+    const i64 ngroups = D >= 16 ? nvox / 16 : 0;      // whole groups of 16 voxels of the flat stream; the rest goes voxel by voxel
+    if (ngroups) {
+        if (D % 16 == 0)
+            hipLaunchKernelGGL(k_color_apply16<false>, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 8)), dim3(256), 0, ctx->stream, d_carved,
+                               d_rgb_hw3, d_out, W, H, D, ngroups);
+        else
+            hipLaunchKernelGGL(k_color_apply16<true>, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 8)), dim3(256), 0, ctx->stream, d_carved,
+                               d_rgb_hw3, d_out, W, H, D, ngroups);
+        PB3D_CHECK_LAUNCH();
     }
+    if (16 * ngroups < nvox)
+        hipLaunchKernelGGL(k_color_apply_generic, dim3(pb3d_stream_blocks(ctx, nvox - 16 * ngroups, 256, 8)), dim3(256), 0, ctx->stream,
+                           d_carved, d_rgb_hw3, d_out, W, H, D, 16 * ngroups);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

@@ -164,7 +164,9 @@ def test_projection_synth_modes_golden(pb3d_gpu, golden):
 def test_carve_vs_oracle_shapes(pb3d_gpu, oracle):
     rng = np.random.default_rng(7)
     shapes = [(1, 1, 1), (3, 2, 5), (17, 9, 16), (8, 5, 48), (64, 64, 64), (5, 7, 1024), (33, 31, 100), (2, 130, 16),
-              (40, 3, 1040), (9, 9, 2741)]
+              (40, 3, 1040), (9, 9, 2741),
+              # column sizes that are not multiples of 16 bytes: the flat-stream kernel (pieces straddling two columns)
+              (7, 5, 17), (11, 4, 355), (2, 3, 21), (6, 5, 4099), (3, 2, 15), (37, 29, 123), (5, 5, 16), (1, 7, 33)]
     for (W, H, D) in shapes:
         for nd in (3, 4):
             grid = rng.integers(0, 256, (W, H, D) + ((3,) if nd == 4 else ()), dtype=np.uint8)
@@ -193,7 +195,10 @@ def test_process_vs_oracle_angles(pb3d_gpu, oracle):
 def test_color_apply_and_occupancy_vs_oracle(pb3d_gpu, oracle):
     rng = np.random.default_rng(13)
     from pb3d.voxel_carving_utils import _occupancy
-    for (W, H, D) in [(16, 9, 16), (5, 4, 7), (32, 3, 64), (3, 3, 33)]:
+    # D % 16 == 0: one column per 16-voxel group; other D >= 16: groups of the flat stream straddle two columns (+ voxel tail);
+    # D < 16: voxel by voxel
+    for (W, H, D) in [(16, 9, 16), (5, 4, 7), (32, 3, 64), (3, 3, 33), (7, 5, 17), (11, 6, 355), (9, 13, 123), (4, 3, 31), (1, 1, 16),
+                      (2, 5, 19)]:
         carved = rng.integers(0, 3, (W, H, D), dtype=np.uint8)  # values 0,1,2: only == 1 is coloured
         rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         assert np.array_equal(pb3d_gpu.apply_colored_mask_to_voxel_grid(carved, rgb), oracle.apply_colored_mask_to_voxel_grid(carved, rgb))

@@ -30,9 +30,17 @@ def main():
         d_rgb = dev.from_numpy(rgb)
         occ = (rng.random((W, H, D)) < 0.6).astype(np.uint8)
         d_occ = dev.from_numpy(occ); d_o = dev.DeviceBuffer(nvox); d_t = dev.DeviceBuffer(nvox); d_col = dev.DeviceBuffer(nvox * 3)
+        sem = rng.integers(0, 255, (W, H, D, 3), dtype=np.uint8)
+        d_sem = dev.from_numpy(sem); d_sem2 = dev.DeviceBuffer(nvox * 3)
+        rows0 = {"carve_voxel_grid_with_masks(sem)": (timeit(lambda: dev.carve_mask(d_sem, W, H, D, 3, d_mwh, d_sem2)), 6),
+                 "carve_voxel_grid_with_masks(occ)": (timeit(lambda: dev.carve_mask(d_occ, W, H, D, 1, d_mwh, d_o)), 2),
+                 "_occupancy": (timeit(lambda: dev.occupancy(d_sem, nvox, d_o)), 4),
+                 "apply_colored_mask": (timeit(lambda: dev.color_apply(d_occ, W, H, D, d_rgb, d_sem2)), 4)}
+        d_sem.free(); d_sem2.free()
         rows = {"process_voxel_grid(occ,90)": (timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t)), 2),
                 "process_voxel_grid(occ,45) per step": (timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 45, d_o, d_t)) / 2, 2),
                 "global_carve(90)": (timeit(lambda: dev.global_carve(d_bhw, d_rgb, H, W, 90, d_col)), 3)}
+        rows.update(rows0)
         for name, (ms, bpv) in rows.items():
             print(json.dumps({"shape": [W, H, D], "op": name, "ms": round(ms, 4), "Mvoxel_s": round(nvox / ms / 1e3, 1),
                               "alg_GB_s": round(bpv * nvox / ms / 1e6, 1)}), flush=True)
