@@ -149,7 +149,9 @@ typedef u32 u32_u __attribute__((aligned(1)));
 // from the image rows bin_hw[y, :] staged in LDS, and the RGBRGB.. / keep byte patterns are cut out
 // of 20-byte sequences with v_alignbyte at the lane's phase.
 // ------------------------------------------------------------------------------------------------
-template <int TYC>
+// RAGGED: 3*D is not a multiple of 16 -- the last piece of a column is short (stored as dwords + bytes); columns then start
+// at arbitrary byte addresses, which 16-byte stores take as they are.
+template <int TYC, bool RAGGED>
 __global__ __launch_bounds__(256) void k_global_carve90v(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3,
                                                          u8* __restrict__ out_slab, const u32* __restrict__ vbits, int nw, int c0,
                                                          i64 W, i64 H, i64 D, i64 x_first, i64 x_last) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void k_global_carve90v(const u8* __restrict__ 
     }
     __syncthreads();
     if (x >= x_last) return;
-    const i64 npieces = 3 * D / 16;
+    const i64 npieces = (3 * D + 15) / 16;
     for (i64 pc = lane; pc < npieces; pc += 64) {
         const int v0 = (int)((16 * pc) / 3);
         const u32 ph = (u32)(pc % 3);
@@ -201,32 +203,14 @@ __global__ __launch_bounds__(256) void k_global_carve90v(const u8* __restrict__ 
                 r.z = __builtin_amdgcn_alignbyte(S0, S2, ph) & __builtin_amdgcn_alignbyte(w3, w2, ph);
                 r.w = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w4, w3, ph);
             }
-            __builtin_nontemporal_store(r, (u32x4*)(out_slab + ((x - x_first) * H + y) * D * 3) + pc);
-        }
-    }
-}
-
-// byte-store variant for widths that are not multiples of 16 (columns not 16-byte aligned)
-template <int TYC>
-__global__ __launch_bounds__(256) void k_global_carve90b(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3,
-                                                         u8* __restrict__ out_slab, const u32* __restrict__ vbits, int nw, int c0,
-                                                         i64 W, i64 H, i64 D, i64 x_first, i64 x_last) {
-    extern __shared__ u8 rows[];
-    const int lane = threadIdx.x & 63;
-    const i64 x = x_first + (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const i64 y_beg = (i64)blockIdx.y * TYC;
-    const i64 y_end = y_beg + TYC < H ? y_beg + TYC : H;
-    for (i64 i = threadIdx.x; i < (y_end - y_beg) * W; i += 256) rows[i] = bin_hw[y_beg * W + i] ? 1 : 0;
-    __syncthreads();
-    if (x >= x_last) return;
-    for (i64 z = lane; z < D; z += 64) {
-        const bool valid = (vbits[x * nw + (z >> 5)] >> (z & 31)) & 1u;
-        for (i64 y = y_beg; y < y_end; ++y) {
-            const u8* row = rows + (y - y_beg) * W;
-            const bool on = valid && row[x] && row[c0 - z];
-            const u8* px = rgb_hw3 + (y * W + x) * 3;
-            u8* o = out_slab + (((x - x_first) * H + y) * D + z) * 3;
-            o[0] = on ? px[0] : (u8)0; o[1] = on ? px[1] : (u8)0; o[2] = on ? px[2] : (u8)0;
+            u8* op = out_slab + ((x - x_first) * H + y) * D * 3 + 16 * pc;
+            if (!RAGGED || 16 * pc + 16 <= 3 * D) __builtin_nontemporal_store(r, (u32x4_u*)op);
+            else {
+                const u32 t4[4] = {r.x, r.y, r.z, r.w};
+                const int k = (int)(3 * D - 16 * pc);                  // 1..15 bytes
+                for (int j = 0; j < (k >> 2); ++j) *(u32_u*)(op + 4 * j) = t4[j];
+                for (int b = k & ~3; b < k; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+            }
         }
     }
 }
@@ -640,12 +624,11 @@ int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rg
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
     dim3 grid((unsigned)((x1 - x0 + 3) / 4), (unsigned)((H + TYC - 1) / TYC));
     PB3D_REQUIRE(grid.y <= 65535u, "pb3d_global_carve: grid too large");
-    const bool vec = (D % 16 == 0) && (((uintptr_t)d_out_slab & 15u) == 0);
-    if (vec)
-        hipLaunchKernelGGL(k_global_carve90v<TYC>, grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
+    if ((3 * D) % 16 == 0)
+        hipLaunchKernelGGL((k_global_carve90v<TYC, false>), grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
                            (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
     else
-        hipLaunchKernelGGL(k_global_carve90b<TYC>, grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
+        hipLaunchKernelGGL((k_global_carve90v<TYC, true>), grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
                            (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
