@@ -385,7 +385,10 @@ __device__ __forceinline__ u32x4 occ16_of(const u32x4 a, const u32x4 b, const u3
 
 // RGBSRC: the source occupancy any(colored > 0) is formed on the fly from the colour grid itself (3 B/voxel read)
 // instead of from a separate occupancy volume.
-template <bool RGBSRC>
+// RAGGED = false: D % 16 == 0 and c2 % 16 == 0 (every 16-voxel piece whole); true: any D / c2 -- pieces at arbitrary byte
+// addresses, the piece across a row end read whole inside the volume (its foreign voxels are void under the validity bits),
+// the short last piece of an output row stored as dwords + bytes.
+template <bool RGBSRC, bool RAGGED>
 __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, const u8* __restrict__ occ, const u32* __restrict__ A,
                                                 const u32* __restrict__ vbits, int nw, int c0, int c2, i64 W, i64 H, i64 D, int TY,
                                                 u8* __restrict__ out) {
@@ -399,7 +402,8 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
     const int cb = tid & 7;
     const i64 rbase = (i64)c0 - (z0 + 127);
     const i64 scol = x0 + c2 + 16 * cb;
-    const bool col_ok = scol >= 0 && scol + 15 < D;
+    const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((RAGGED && scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
+    const i64 nvox_all = W * H * D;
     const int zg = tid & 7, xg = tid >> 3;
     const int g = 7 - zg;
     const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
@@ -418,13 +422,32 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
-            const bool ok = col_ok && n0 >= 0 && n0 < W;
+            const bool ok = cmode && n0 >= 0 && n0 < W;
+            const i64 v0s = (n0 * H + y) * D + scol;                       // first source voxel of the piece
+            const bool whole = !RAGGED || cmode == 2 || (v0s >= 0 && v0s + 16 <= nvox_all);
             if (RGBSRC) {
-                const u32x4* sp = (const u32x4*)(colored + ((n0 * H + y) * D + scol) * 3);
+                const u8* sp8 = colored + v0s * 3;
+                if (whole) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) stg[3 * j + k] = ok ? sp[k] : (u32x4)(0u);
+                    for (int k = 0; k < 3; ++k) stg[3 * j + k] = ok ? ((const u32x4_u*)sp8)[k] : (u32x4)(0u);
+                } else {
+                    u32 t12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok)
+                        for (int b = 0; b < 48; ++b)
+                            if (scol + b / 3 >= 0 && scol + b / 3 < D) t12[b >> 2] |= (u32)sp8[b] << (8 * (b & 3));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { stg[3 * j + k].x = t12[4 * k]; stg[3 * j + k].y = t12[4 * k + 1]; stg[3 * j + k].z = t12[4 * k + 2]; stg[3 * j + k].w = t12[4 * k + 3]; }
+                }
             } else {
-                stg[j] = ok ? *(const u32x4*)(occ + (n0 * H + y) * D + scol) : (u32x4)(0u);
+                const u8* sp8 = occ + v0s;
+                if (whole) stg[j] = ok ? *(const u32x4_u*)sp8 : (u32x4)(0u);
+                else {
+                    u32 t4[4] = {0, 0, 0, 0};
+                    if (ok)
+                        for (int b = 0; b < 16; ++b)
+                            if (scol + b >= 0 && scol + b < D) t4[b >> 2] |= (u32)sp8[b] << (8 * (b & 3));
+                    stg[j].x = t4[0]; stg[j].y = t4[1]; stg[j].z = t4[2]; stg[j].w = t4[3];
+                }
             }
         }
         if (tid < 128) {
@@ -486,7 +509,8 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
                 const int pc = pl + 8 * kk;
-                if ((i64)16 * pc + 16 > row_bytes) continue;
+                if (RAGGED ? (i64)16 * pc >= row_bytes : (i64)16 * pc + 16 > row_bytes) continue;
+                const int nb = RAGGED && (i64)16 * pc + 16 > row_bytes ? (int)(row_bytes - 16 * pc) : 16;   // bytes of this piece
                 const int v0 = (16 * pc) / 3;
                 const u32 ph = (u32)(pc % 3);
                 const int wi = v0 >> 4;
@@ -494,7 +518,13 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
                 const u32 kb6 = (win >> (v0 & 15)) & 0x3fu;
                 u32x4 val = (u32x4)(0u);
                 if (kb6) {
-                    const u32x4 src = *(const u32x4*)(srow + 16 * pc);
+                    u32x4 src;
+                    if (nb == 16 || ((x * H + y) * D + z0) * 3 + 16 * pc + 16 <= nvox_all * 3) src = *(const u32x4_u*)(srow + 16 * pc);
+                    else {
+                        u32 t4[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < nb; ++b) t4[b >> 2] |= (u32)srow[16 * pc + b] << (8 * (b & 3));
+                        src.x = t4[0]; src.y = t4[1]; src.z = t4[2]; src.w = t4[3];
+                    }
                     u32 m[6];
 #pragma unroll
                     for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
@@ -506,7 +536,13 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
                     val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
                     val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
                 }
-                __builtin_nontemporal_store(val, (u32x4*)(drow + 16 * pc));
+                if (nb == 16) __builtin_nontemporal_store(val, (u32x4_u*)(drow + 16 * pc));
+                else {
+                    const u32 t4[4] = {val.x, val.y, val.z, val.w};
+                    u8* op = drow + 16 * pc;
+                    for (int jj = 0; jj < (nb >> 2); ++jj) *(u32_u*)(op + 4 * jj) = t4[jj];
+                    for (int b = nb & ~3; b < nb; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+                }
             }
         }
         __syncthreads();
@@ -653,8 +689,8 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     if (!pb3d_is_perm_step(M, off, W, D)) return PB3D_EUNSUPPORTED;
     const PermMap pm = perm_map(M, off);
     const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
-    if (!(rot90 && D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_colored | (uintptr_t)d_out) & 15u) == 0 && W <= 65535 && H <= 65535))
-        return PB3D_EUNSUPPORTED;
+    if (!(rot90 && W <= 65535 * 128 && H <= 65535)) return PB3D_EUNSUPPORTED;
+    const bool ragged = !(D % 16 == 0 && pm.c2 % 16 == 0);
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     u32* bits; int nw;
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
@@ -678,12 +714,9 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
     while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
     dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
-    if (rgbsrc)
-        hipLaunchKernelGGL(k_part90<true>, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw,
-                           pm.c0, pm.c2, W, H, D, TY, d_out);
-    else
-        hipLaunchKernelGGL(k_part90<false>, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw,
-                           pm.c0, pm.c2, W, H, D, TY, d_out);
+    auto kern = rgbsrc ? (ragged ? k_part90<true, true> : k_part90<true, false>) : (ragged ? k_part90<false, true> : k_part90<false, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw, pm.c0, pm.c2,
+                       W, H, D, TY, d_out);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

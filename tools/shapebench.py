@@ -40,6 +40,18 @@ def main():
         rows = {"process_voxel_grid(occ,90)": (timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t)), 2),
                 "process_voxel_grid(occ,45) per step": (timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 45, d_o, d_t)) / 2, 2),
                 "global_carve(90)": (timeit(lambda: dev.global_carve(d_bhw, d_rgb, H, W, 90, d_col)), 3)}
+        # part_carve with six 90-degree jobs: label image -> six disjoint sub-masks (the (W,H) images the C-ABI takes)
+        import ctypes as C
+        lab = rng.integers(0, 7, (W, H), dtype=np.uint8) * m_hw.T
+        msub = np.stack([(lab == j + 1).astype(np.uint8) for j in range(6)])
+        d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(msub)
+        dev.global_carve(d_bhw, d_rgb, H, W, 90, d_col)
+        d_pout = dev.DeviceBuffer(nvox * 3)
+        L, lib = pb3d._lib, pb3d._lib.load()
+        ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*([0] * 6))
+        rows0["part_carve(6 x 90 deg)"] = (timeit(lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), W, H, D, C.c_void_p(d_ms.ptr),
+                                                                                        C.c_void_p(d_mc.ptr), ang, skip, 6, C.c_void_p(d_pout.ptr))), 3), 9)
+        d_ms.free(); d_mc.free(); d_pout.free()
         rows.update(rows0)
         for name, (ms, bpv) in rows.items():
             print(json.dumps({"shape": [W, H, D], "op": name, "ms": round(ms, 4), "Mvoxel_s": round(nvox / ms / 1e3, 1),
