@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every rank carves its own full S^3 grid (default: the ONE "
+                    "S^3 grid of the BASELINE metric is split into X-slabs = strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,13 +124,16 @@ def main():
     pb3d._lib.ctx()
     info = dev.device_info()
 
-    planes = pdist.equal_slabs(S, world)
-    x0, x1 = rank * planes, (rank + 1) * planes
+    planes = S if args.weak else pdist.equal_slabs(S, world)
+    x0, x1 = (0, S) if args.weak else (rank * planes, (rank + 1) * planes)
+    if args.weak:
+        args.seed += rank
+        args.no_allgather = True        # independent grids: nothing to reassemble
     slab_vox = planes * S * S
     slab_bytes = slab_vox * 3
     d_in = dev.DeviceBuffer(slab_bytes)
-    d_full = dev.DeviceBuffer(slab_bytes * world)        # the reassembled volume; this rank's slab lives at its slot
-    d_out = d_full.at(rank * slab_bytes)
+    d_full = dev.DeviceBuffer(slab_bytes * (1 if args.weak else world))   # the reassembled volume; this rank's slab lives at its slot
+    d_out = d_full.at(0 if args.weak else rank * slab_bytes)
     d_mwh = dev.DeviceBuffer(S * S)
     dev.synth_sem(x0, x1, S, S, args.seed, d_in)
     dev.synth_mask16(S, d_binary_wh=d_mwh)
@@ -155,15 +160,16 @@ def main():
     kernel_ms = e1.elapsed_ms_since(e0) / args.steps     # HIP events on the stream the kernel runs on
     kernel_ms_max = cp.allreduce_max(kernel_ms)
 
-    total_vox = S * S * S
+    total_vox = planes * world * S * S
     value = total_vox * args.steps / t / 1e6
     achieved = ALG_BYTES_PER_VOXEL * slab_vox / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": f"Mvoxel/s carved (semantic carve, {S}^3 grid)", "value": round(value, 1), "unit": "Mvoxel/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"configs[3]: synthetic 16-label mask, {S}^3 semantic RGB grid, op M1 "
-                               f"carve_voxel_grid_with_masks(sem, binary); X-slab partition over {world} GPU(s)",
+                               f"carve_voxel_grid_with_masks(sem, binary); " +
+                               (f"one such grid per GPU, {world} GPU(s)" if args.weak else f"X-slab partition over {world} GPU(s)"),
                    "grid": [S, S, S, 3], "slab_planes_per_gpu": planes, "seed": args.seed, "device": info["name"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_carve_tiles", slab_vox),
