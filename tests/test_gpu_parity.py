@@ -619,3 +619,21 @@ def test_points_colour_sets_hash_probe(pb3d_gpu, oracle):
         gp, gc, _ = pb3d_gpu.voxel_grid_to_points(grid, stride=1)
         op, oc, _ = oracle.voxel_grid_to_points(grid, stride=1)
         assert np.array_equal(gp, op) and np.array_equal(gc, oc), shp
+
+
+@pytest.mark.gpu
+def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
+    """the fused 90-degree part_carve kernel on shapes the reference's own grids never have (W != D, odd D, non-zero column
+    offset of either sign, rows at arbitrary byte alignment), foreign colours included; mixed-angle jobs beside it."""
+    rng = np.random.default_rng(101)
+    PC = oracle.PART_COLORS
+    names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
+    pal = np.array([PC[n] for n in names] + [(0, 0, 0), (9, 9, 9)], np.uint8)
+    for (W, H, D) in [(37, 9, 51), (51, 5, 37), (130, 6, 62), (355, 4, 355), (129, 3, 131), (16, 7, 48), (200, 3, 72)]:
+        sem = pal[rng.integers(0, 7, (H, W))]                              # (H,W,3) semantic mask: part colours + black
+        colored = pal[rng.integers(0, len(pal), (W, H, D))]                # (W,H,D,3): part colours, black, a foreign colour
+        colored[rng.random((W, H, D)) < 0.3] = 0
+        for jobs in (JOBS_NB1, JOBS_MIXED):
+            got = pb3d_gpu.part_carve(colored, sem, jobs)
+            want = oracle.part_carve(colored, sem, jobs)
+            assert np.array_equal(got, want), (W, H, D, len(jobs), int((got != want).sum()))
