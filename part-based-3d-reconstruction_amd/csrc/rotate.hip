@@ -586,6 +586,268 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
     if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide-tile form for large grids: 128 x 128 (x,z) output tiles, 16 planes per pass (one u16 per staged source voxel).
+// k_rotate_bits32 fetches 2.7 GB for 1.07 GB of input at 1024^3: its 64-wide tiles cut the source rows into ~64-byte
+// segments of 128-byte lines, and its 64-byte output runs are half lines.  Here a footprint row is up to 181 bytes
+// (lines touched per tile ~ T^2/128 + sqrt(2) T: 2.4x at T = 128 against 3.8x at T = 64 before the L2) and every
+// output run is a whole 128-byte line.  The table evaluation serves 16 planes per mux tree instead of 32 -- it was
+// 1 % of the time.  512 threads x 32 cells; LDS 184 x 208 x 2 B (two workgroups per CU).  Measured at 1024^3, 45 degrees:
+// FETCH_SIZE 2.04 GB (64-wide tiles: 2.72 GB), 0.66 ms against 0.74 ms; phase ablation: staging 0.35 ms, stores 0.24 ms.
+// ------------------------------------------------------------------------------------------------
+constexpr int XT = 128, XTHREADS = 512, XCELLS = 32, XTPR = XT / XCELLS;
+constexpr int XROWS = 184, XPITCH = 208;
+constexpr int XMAXU = (XROWS * (XPITCH / 16) + XTHREADS - 1) / XTHREADS;
+
+// Footprint of every 128 x 128 tile, once per step (it does not depend on the plane): bounding box and, per footprint row,
+// the leftmost / rightmost tap column.  ~64 K LDS atomics per tile -- done here once instead of once per (tile, plane block),
+// by four workgroups per tile (32 x-rows each, rows relative to the quarter's own first row); the tile kernel merges the four.
+struct TileRows { int bb[4]; short rmin[XROWS], rmax[XROWS]; };
+constexpr int XQ = 4;
+
+__global__ __launch_bounds__(XTHREADS) void k_rot_tile_rows(const CellRec* __restrict__ cells, i64 W, i64 D, int ntz, TileRows* __restrict__ info) {
+    __shared__ int bb[4];
+    __shared__ int rmin[XROWS], rmax[XROWS];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x / XQ, quarter = blockIdx.x % XQ;
+    const i64 x0 = (i64)(t / ntz) * XT, z0 = (i64)(t % ntz) * XT;
+    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+    if (tid < XROWS) { rmin[tid] = 0x7fffffff; rmax[tid] = -1; }
+    __syncthreads();
+    // 512 threads on 32 x-rows x 128 z: 16 threads per row, 8 cells each
+    constexpr int QC = XT / 16;
+    const int zl = (tid % 16) * QC, xl0 = quarter * (XT / XQ) + tid / 16;
+    const i64 x = x0 + xl0;
+    int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
+    if (x < W) {
+        for (int c = 0; c < QC; ++c) {
+            const i64 z = z0 + zl + c;
+            if (z >= D) break;
+            const CellRec r = cells[x * D + z];
+            if (r.src == 0xffffffffu) continue;
+            const int s0 = (int)(r.src >> 16), s2 = (int)(r.src & 0xffffu);
+            const int e0 = s0 + (int)((r.lut >> 16) & 1u), e2 = s2 + (int)((r.lut >> 17) & 1u);
+            mn0 = s0 < mn0 ? s0 : mn0; mx0 = e0 > mx0 ? e0 : mx0;
+            mn2 = s2 < mn2 ? s2 : mn2; mx2 = e2 > mx2 ? e2 : mx2;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn0 = min(mn0, __shfl_xor(mn0, o)); mx0 = max(mx0, __shfl_xor(mx0, o));
+        mn2 = min(mn2, __shfl_xor(mn2, o)); mx2 = max(mx2, __shfl_xor(mx2, o));
+    }
+    if ((tid & 63) == 0 && mx0 >= 0) { atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); atomicMin(&bb[2], mn2); atomicMax(&bb[3], mx2); }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1];
+    const bool fits = bx1 >= 0 && bx1 - bx0 + 2 <= XROWS;
+    if (fits && x < W) {
+        for (int c = 0; c < QC; ++c) {
+            const i64 z = z0 + zl + c;
+            if (z >= D) break;
+            const CellRec r = cells[x * D + z];
+            if (r.src == 0xffffffffu) continue;
+            const int rr = (int)(r.src >> 16) - bx0, s2 = (int)(r.src & 0xffffu);
+            const int e2 = s2 + (int)((r.lut >> 17) & 1u);
+            atomicMin(&rmin[rr], s2); atomicMax(&rmax[rr], e2);
+            if ((r.lut >> 16) & 1u) { atomicMin(&rmin[rr + 1], s2); atomicMax(&rmax[rr + 1], e2); }
+        }
+    }
+    __syncthreads();
+    TileRows* o = info + (i64)t * XQ + quarter;
+    if (tid < 4) o->bb[tid] = fits ? bb[tid] : (tid == 1 && bx1 >= 0 ? 0x7ffffff0 : bb[tid]);   // a quarter that does not fit poisons the tile's box
+    if (tid < XROWS) { o->rmin[tid] = (short)(rmax[tid] >= 0 ? rmin[tid] : 0); o->rmax[tid] = (short)rmax[tid]; }
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(XTHREADS, 4) void k_rotate_bits16w(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
+                                                                const CellRec* __restrict__ cells, const TileRows* __restrict__ info, i64 W, i64 H,
+                                                                i64 D, int TY, int ntz, int ntiles, int* __restrict__ big_flag) {
+    extern __shared__ __attribute__((aligned(16))) u8 xlds[];
+    unsigned short* tile = (unsigned short*)xlds;                                  // XROWS * XPITCH
+    int* rmin = (int*)(xlds + XROWS * XPITCH * 2);                                 // XROWS
+    int* rmax = rmin + XROWS;                                                      // XROWS
+    unsigned short* ustart = (unsigned short*)(rmax + XROWS);                      // XROWS + 1 (+1 pad)
+    u8* rc0 = (u8*)(ustart + XROWS + 2);                                           // XROWS
+    u8* urow = rc0 + XROWS;                                                        // XROWS * XPITCH / 16
+    int* bb = (int*)(xlds + XROWS * XPITCH * 2 + 2 * XROWS * 4 + (XROWS + 2) * 2 + XROWS + XROWS * (XPITCH / 16) + 8);
+    bb = (int*)(((uintptr_t)bb + 3) & ~(uintptr_t)3);
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+    typedef u32 u32_a1 __attribute__((aligned(1)));
+    const int tid = threadIdx.x;
+    const int chunk = (ntiles + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int t = (int)(blockIdx.x & 7u) * chunk + slot % chunk;
+    if (t >= ntiles) return;                          // whole workgroup, before any barrier
+    const i64 x0 = (i64)(t / ntz) * XT, z0 = (i64)(t % ntz) * XT;
+    const i64 y_beg = (i64)(slot / chunk) * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    const TileRows* qi = info + (i64)t * XQ;
+    if (tid == 0) {
+        int b0 = 0x7fffffff, b1 = -1, b2 = 0x7fffffff, b3 = -1;
+        for (int q = 0; q < XQ; ++q)
+            if (qi[q].bb[1] >= 0) { b0 = min(b0, qi[q].bb[0]); b1 = max(b1, qi[q].bb[1]); b2 = min(b2, qi[q].bb[2]); b3 = max(b3, qi[q].bb[3]); }
+        bb[0] = b0; bb[1] = b1; bb[2] = b2; bb[3] = b3;
+    }
+    __syncthreads();
+    if (tid < XROWS) {                                // row tid of the tile's box = row tid + bb[0] - bb_q[0] of quarter q
+        int lo = 0x7fffffff, hi = -1;
+        for (int q = 0; q < XQ; ++q) {
+            if (qi[q].bb[1] < 0) continue;
+            const int rq = tid + bb[0] - qi[q].bb[0];
+            if (rq >= 0 && rq < XROWS && qi[q].rmax[rq] >= 0) { lo = min(lo, (int)qi[q].rmin[rq]); hi = max(hi, (int)qi[q].rmax[rq]); }
+        }
+        rmin[tid] = lo; rmax[tid] = hi;
+    }
+    __syncthreads();
+    const int zl = (tid % XTPR) * XCELLS, xl0 = tid / XTPR;
+    const i64 x = x0 + xl0;
+    const bool row_ok = x < W && z0 + zl < D;
+    const int bx0 = bb[0], bx1 = bb[1], bz0 = bb[2] & ~15, bz1 = bb[3];
+    const bool any_valid = bx1 >= 0;
+    const int nrows = any_valid ? bx1 - bx0 + 1 : 0;
+    const int nu = any_valid ? (bz1 - bz0) / 16 + 1 : 0;
+    const bool fits = nrows + 1 <= XROWS && nu * 16 <= XPITCH;
+    if (any_valid && !fits) { if (tid == 0) atomicOr(big_flag, 1); }
+    u32 cellw[XCELLS];                                // table << 16 | LDS offset (0xffff: outputs 0)
+#pragma unroll
+    for (int c = 0; c < XCELLS; ++c) cellw[c] = 0xffffu;
+    if (row_ok && fits) {
+        typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+        const u32x4_a8* cp = (const u32x4_a8*)(cells + x * D + z0 + zl);      // XCELLS records (the table is padded)
+#pragma unroll
+        for (int k = 0; k < XCELLS / 2; ++k) {
+            const u32x4 v = cp[k];
+            const bool ok0 = !RAGGED || z0 + zl + 2 * k < D, ok1 = !RAGGED || z0 + zl + 2 * k + 1 < D;
+            if (ok0 && v.x != 0xffffffffu) cellw[2 * k] = (v.y << 16) | (u32)(((int)(v.x >> 16) - bx0) * XPITCH + ((int)(v.x & 0xffffu) - bz0));
+            if (ok1 && v.z != 0xffffffffu) cellw[2 * k + 1] = (v.w << 16) | (u32)(((int)(v.z >> 16) - bx0) * XPITCH + ((int)(v.z & 0xffffu) - bz0));
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                    // wave 0: exclusive scan of the per-row unit counts (rows tid, tid+64, tid+128)
+        int n[3], inc[3];
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int r = tid + 64 * h;
+            n[h] = 0;
+            if (r < nrows && fits && rmax[r] >= 0) {
+                rc0[r] = (u8)((rmin[r] - bz0) >> 4);
+                n[h] = ((rmax[r] - bz0) >> 4) - ((rmin[r] - bz0) >> 4) + 1;
+            } else if (r < XROWS) rc0[r] = 0;
+            inc[h] = n[h];
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) { const int a = __shfl_up(inc[h], o); if (tid >= o) inc[h] += a; }
+        }
+        const int tot0 = __shfl(inc[0], 63), tot1 = tot0 + __shfl(inc[1], 63);
+        ustart[tid] = (unsigned short)(inc[0] - n[0]);
+        ustart[tid + 64] = (unsigned short)(tot0 + inc[1] - n[1]);
+        if (tid + 128 <= XROWS) ustart[tid + 128] = (unsigned short)(tot1 + inc[2] - n[2]);
+        if (tid == 63) ustart[XROWS] = (unsigned short)(tot1 + inc[2]);
+    }
+    __syncthreads();
+    const int nunits = (any_valid && fits) ? (int)ustart[XROWS] : 0;
+    if (tid < nrows && fits) {
+        const int u0 = ustart[tid], u1 = ustart[tid + 1];
+        for (int u = u0; u < u1; ++u) urow[u] = (u8)tid;
+    }
+    __syncthreads();
+    u32 hib = 0;
+    for (i64 yg = y_beg; yg < y_end; yg += 16) {
+        const int np = (int)(y_end - yg < 16 ? y_end - yg : 16);
+        u32 mbits = 0;
+        if (row_ok) {
+            if (!mask_wh) mbits = 0xffffu;
+            else for (int q = 0; q < np; ++q) mbits |= (u32)(mask_wh[x * H + yg + q] != 0) << q;
+        }
+        // ---- stage the footprint of 16 planes: 16 voxels x 16 planes per unit, 8 planes of 16-byte loads in flight per lane
+#pragma unroll 1
+        for (int j = 0; j < XMAXU; ++j) {
+            const int i = tid + XTHREADS * j;
+            if (i >= nunits) break;
+            const int r = urow[i];
+            const int cu = (int)rc0[r] + (i - (int)ustart[r]);
+            const u32 voff = (u32)(((i64)bx0 + r) * H * D + (i64)bz0 + 16 * cu);
+            const bool whole = !RAGGED || (i64)bz0 + 16 * cu + 15 < D || (i64)voff + (yg + 15) * D + 16 <= W * H * D;
+            u32x4 wg[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                u32x4 d[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const u8* pb = in + (yg + 8 * g + q) * D;        // uniform
+                    d[q] = (u32x4)(0u);
+                    if (8 * g + q < np) {
+                        if (whole) d[q] = *(const u32x4_a1*)(pb + voff);
+                        else {
+                            u32 t4[4] = {0, 0, 0, 0};
+                            for (int b = 0; (i64)bz0 + 16 * cu + b < D; ++b) t4[b >> 2] |= (u32)pb[voff + b] << (8 * (b & 3));
+                            d[q].x = t4[0]; d[q].y = t4[1]; d[q].z = t4[2]; d[q].w = t4[3];
+                        }
+                    }
+                }
+                u32x4 wv = (u32x4)(0u);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    wv.x |= (d[q].x & 0x01010101u) << q; wv.y |= (d[q].y & 0x01010101u) << q;
+                    wv.z |= (d[q].z & 0x01010101u) << q; wv.w |= (d[q].w & 0x01010101u) << q;
+                    hib |= d[q].x | d[q].y | d[q].z | d[q].w;
+                }
+                wg[g] = wv;
+            }
+            // voxel v of the unit: u16 = planes 0..7 (byte v of wg[0]) | planes 8..15 (byte v of wg[1]) << 8
+            u32x4 lo, hi;
+            lo.x = pperm(wg[1].x, wg[0].x, 0x05010400u); lo.y = pperm(wg[1].x, wg[0].x, 0x07030602u);
+            lo.z = pperm(wg[1].y, wg[0].y, 0x05010400u); lo.w = pperm(wg[1].y, wg[0].y, 0x07030602u);
+            hi.x = pperm(wg[1].z, wg[0].z, 0x05010400u); hi.y = pperm(wg[1].z, wg[0].z, 0x07030602u);
+            hi.z = pperm(wg[1].w, wg[0].w, 0x05010400u); hi.w = pperm(wg[1].w, wg[0].w, 0x07030602u);
+            unsigned short* trow = tile + r * XPITCH + 16 * cu;
+            *(u32x4*)(trow) = lo; *(u32x4*)(trow + 8) = hi;
+        }
+        __syncthreads();
+        // ---- evaluate 32 cells x 16 planes; write np planes of this thread's 32-byte run
+        if (row_ok) {
+            u32 G[XCELLS / 4][2];        // G[i][g]: byte c = planes 8g..8g+7 of cell 4i + c
+#pragma unroll
+            for (int i = 0; i < XCELLS / 4; ++i) {
+                u32 R[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32 cw = cellw[4 * i + c], o = cw & 0xffffu;
+                    R[c] = 0;
+                    if (o != 0xffffu) R[c] = lut_apply32(cw >> 16, tile[o], tile[o + 1], tile[o + XPITCH], tile[o + XPITCH + 1]);
+                }
+                const u32 l01 = pperm(R[1], R[0], 0x05010400u), l23 = pperm(R[3], R[2], 0x05010400u);
+                G[i][0] = pperm(l23, l01, 0x05040100u); G[i][1] = pperm(l23, l01, 0x07060302u);
+            }
+            const u32 ooff = (u32)(x * H * D + z0 + zl);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q >= np) break;
+                const u32 keep = ((mbits >> q) & 1u) ? 0x01010101u : 0u;
+                u32 rr[XCELLS / 4];
+#pragma unroll
+                for (int i = 0; i < XCELLS / 4; ++i) rr[i] = (G[i][q >> 3] >> (q & 7)) & keep;
+                u8* pb = out + (yg + q) * D;                          // uniform
+                if (!RAGGED || z0 + zl + XCELLS <= D) {
+                    u32x4 r0, r1;
+                    r0.x = rr[0]; r0.y = rr[1]; r0.z = rr[2]; r0.w = rr[3]; r1.x = rr[4]; r1.y = rr[5]; r1.z = rr[6]; r1.w = rr[7];
+                    *(u32x4_a1*)(pb + ooff) = r0; *(u32x4_a1*)(pb + ooff + 16) = r1;
+                } else {
+                    const int k = (int)(D - z0 - zl);                  // 1..31 bytes: whole dwords, then bytes
+                    for (int jj = 0; jj < (k >> 2); ++jj) *(u32_a1*)(pb + ooff + 4 * jj) = rr[jj];
+                    for (int b = k & ~3; b < k; ++b) pb[ooff + b] = (u8)(rr[b >> 2] >> (8 * (b & 3)));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
+}
+constexpr size_t kXLds = (size_t)XROWS * XPITCH * 2 + 2 * XROWS * 4 + (XROWS + 2) * 2 + XROWS + XROWS * (XPITCH / 16) + 8 + 4 + 16;
+
 bool is_zero(double v) { return v == 0.0; }
 
 }  // namespace
@@ -616,9 +878,37 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
         PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
         if (H >= 32 && W * H * D < (1ll << 32) - 64) {
             void* cells;
-            PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + WCELLS) * sizeof(CellRec), &cells));
+            PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
             hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells);
             PB3D_CHECK_LAUNCH();
+            const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
+            // PB3D_ROTATE_TILE=64 / 128 pins the tile kernel (parity tests run both on the same grids)
+            const char* pin = getenv("PB3D_ROTATE_TILE");
+            const bool wide = pin ? atoi(pin) == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2);
+            if (wide) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
+                    PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
+                    attr_set = true;
+                }
+                void* trows;
+                PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)xtiles * XQ * sizeof(TileRows), &trows));
+                hipLaunchKernelGGL(k_rot_tile_rows, dim3((unsigned)(xtiles * XQ)), dim3(XTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D,
+                                   (int)((D + XT - 1) / XT), (TileRows*)trows);
+                PB3D_CHECK_LAUNCH();
+                const int TYX = 64;
+                const i64 nblkx = 8 * ((xtiles + 7) / 8) * ((H + TYX - 1) / TYX);
+                PB3D_REQUIRE(nblkx < (1ll << 31), "pb3d_rotate_carve: grid too large");
+                if (D % 16 == 0)
+                    hipLaunchKernelGGL(k_rotate_bits16w<false>, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh,
+                                       (const CellRec*)cells, (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
+                else
+                    hipLaunchKernelGGL(k_rotate_bits16w<true>, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh,
+                                       (const CellRec*)cells, (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
+                PB3D_CHECK_LAUNCH();
+                goto tiled_done;
+            }
             int TYW = 64;        // multiples of 32 planes per workgroup (measured at 1024^3: 32/64 planes 0.76 ms, 128: 0.79, 256: 0.88)
             while (TYW > 32 && tiles * ((H + TYW - 1) / TYW) < (i64)ctx->cus * 4) TYW >>= 1;
             const i64 nblk = 8 * ((tiles + 7) / 8) * ((H + TYW - 1) / TYW);
@@ -635,6 +925,7 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
             hipLaunchKernelGGL(k_rotate_bits<false>, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
         PB3D_CHECK_LAUNCH();
     }
+tiled_done:
     int TY = tiled ? 64 : 16;      // after a table-driven step the grid only reads the flag: keep that launch small
     // keep at least ~8 blocks per CU in flight for small grids
     const i64 tiles_xz = ((D + 255) / 256) * ((W + 3) / 4);

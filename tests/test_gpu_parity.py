@@ -522,9 +522,14 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
         g_one_big = g_bin.copy(); g_one_big[W // 2, H // 2, D // 2] = 200      # a single value > 1 must switch the whole step
         for ai in (45, 30, 50):
             for g in (g_bin, g_full, g_one_big):
-                got = pb3d_gpu.process_voxel_grid(g, m, ai)
                 want = oracle.process_voxel_grid(g, m, ai)
-                assert np.array_equal(got, want), (W, H, D, ai, int((got != want).sum()))
+                for tile in ("64", "128"):         # the 64x64 / 32-plane and the 128x128 / 16-plane kernels (the library picks by size)
+                    os.environ["PB3D_ROTATE_TILE"] = tile
+                    try:
+                        got = pb3d_gpu.process_voxel_grid(g, m, ai)
+                    finally:
+                        del os.environ["PB3D_ROTATE_TILE"]
+                    assert np.array_equal(got, want), (W, H, D, ai, tile, int((got != want).sum()))
 
 
 def test_random_shapes_property(pb3d_gpu, oracle):
