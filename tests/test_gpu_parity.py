@@ -642,3 +642,37 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
             got = pb3d_gpu.part_carve(colored, sem, jobs)
             want = oracle.part_carve(colored, sem, jobs)
             assert np.array_equal(got, want), (W, H, D, len(jobs), int((got != want).sum()))
+
+
+@pytest.mark.gpu
+def test_full_size_process_grid_45_against_oracle_slab(pb3d_gpu, oracle):
+    """process_voxel_grid(occ, binary, 45) on the 1024^3 synthetic grid, device resident (0-degree carve, two generic-angle
+    steps through the wide-tile bit-sliced kernel, the 90-degree step through k_rot90).  A rotation about Y never mixes
+    Y-planes, so a slab of planes of the full result must equal the oracle run on that slab alone; and the two generic-angle
+    tile kernels (64 x 64 / 32 planes, 128 x 128 / 16 planes), written independently, must agree on the whole volume."""
+    import synth_host
+    from pb3d import device as dev
+    S = int(os.environ.get("PB3D_TEST_FULL_SIZE", "1024"))
+    nvox = S * S * S
+    d_occ = dev.DeviceBuffer(nvox); d_out = dev.DeviceBuffer(nvox); d_tmp = dev.DeviceBuffer(nvox); d_out64 = dev.DeviceBuffer(nvox)
+    d_mwh = dev.DeviceBuffer(S * S)
+    dev.synth_occ(0, S, S, S, 0, d_occ)
+    dev.synth_mask16(S, d_binary_wh=d_mwh)
+    lab, binary, rgb = synth_host.mask16(S)                  # (H,W) images
+    dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out, d_tmp)
+    os.environ["PB3D_ROTATE_TILE"] = "64"
+    try:
+        dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out64, d_tmp)
+    finally:
+        del os.environ["PB3D_ROTATE_TILE"]
+    dev.sync()
+    full = d_out.download((S, S, S)); full64 = d_out64.download((S, S, S))
+    assert np.array_equal(full, full64)
+    assert full.max() <= 1 and 0 < int(full.sum()) < nvox
+    occ = d_occ.download((S, S, S))
+    for y0 in (0, S // 2 - 1, S - 3):
+        ys = slice(y0, y0 + 3)
+        want = oracle.process_voxel_grid(np.ascontiguousarray(occ[:, ys, :]), binary[ys, :], 45)
+        assert np.array_equal(full[:, ys, :], want), y0
+    for b in (d_occ, d_out, d_tmp, d_out64, d_mwh):
+        b.free()
