@@ -24,6 +24,7 @@ struct pb3d_ctx {
     int device;
     int cus;
     hipStream_t stream;
+    bool wide_lds_set;          // hipFuncSetAttribute(max dynamic LDS) done for the wide rotate kernel on this device
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).
     void* scratch[PB3D_NSCRATCH];

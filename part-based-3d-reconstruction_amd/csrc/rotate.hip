@@ -852,6 +852,62 @@ bool is_zero(double v) { return v == 0.0; }
 
 }  // namespace
 
+// The table-driven (0/1 data) form of a generic-angle step; *flag is raised on the device when the data was not 0/1.
+//   >= 32 planes: cell table once per step, then the 128 x 128 / 16-plane kernel on large grids or the 64 x 64 / 32-plane one;
+//   fewer planes (or a volume of 4 GiB and more): the 8-plane kernel that evaluates its cells itself.
+static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const RotParams& p, const u8* d_mask_wh, u8* d_out,
+                             int* flag) {
+    const i64 tiles = ((D + LT - 1) / LT) * ((W + LT - 1) / LT);
+    if (!(H >= 32 && W * H * D < (1ll << 32) - 64)) {
+        int TYL = 32;
+        while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
+        dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
+        PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
+        if (D % 16 == 0 && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u) == 0)
+            hipLaunchKernelGGL(k_rotate_bits<true>, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
+        else
+            hipLaunchKernelGGL(k_rotate_bits<false>, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
+    void* cells;
+    PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
+    hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells);
+    PB3D_CHECK_LAUNCH();
+    const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
+    // PB3D_ROTATE_TILE=64 / 128 pins the tile kernel (parity tests run both on the same grids)
+    const char* pin = getenv("PB3D_ROTATE_TILE");
+    const bool wide = pin ? atoi(pin) == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2);
+    if (wide) {
+        if (!ctx->wide_lds_set) {       // > 64 KiB of LDS per workgroup has to be allowed once per device
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
+            ctx->wide_lds_set = true;
+        }
+        void* trows;
+        PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)xtiles * XQ * sizeof(TileRows), &trows));
+        hipLaunchKernelGGL(k_rot_tile_rows, dim3((unsigned)(xtiles * XQ)), dim3(XTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D,
+                           (int)((D + XT - 1) / XT), (TileRows*)trows);
+        PB3D_CHECK_LAUNCH();
+        const int TYX = 64;
+        const i64 nblkx = 8 * ((xtiles + 7) / 8) * ((H + TYX - 1) / TYX);
+        PB3D_REQUIRE(nblkx < (1ll << 31), "pb3d_rotate_carve: grid too large");
+        auto kern = D % 16 == 0 ? k_rotate_bits16w<false> : k_rotate_bits16w<true>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh, (const CellRec*)cells,
+                           (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
+    } else {
+        int TYW = 64;        // multiples of 32 planes per workgroup (measured at 1024^3: 32/64 planes 0.76 ms, 128: 0.79, 256: 0.88)
+        while (TYW > 32 && tiles * ((H + TYW - 1) / TYW) < (i64)ctx->cus * 4) TYW >>= 1;
+        const i64 nblk = 8 * ((tiles + 7) / 8) * ((H + TYW - 1) / TYW);
+        PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
+        auto kern = D % 16 == 0 ? k_rotate_bits32<false> : k_rotate_bits32<true>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh, (const CellRec*)cells, W, H, D,
+                           TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
+    }
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
                                const double off[3], const u8* d_mask_wh, u8* d_out) {
     PB3D_REQUIRE(is_zero(M[3]) && M[4] == 1.0 && is_zero(M[5]) && is_zero(M[1]) && is_zero(M[7]) && is_zero(off[1]),
@@ -871,61 +927,8 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
         PB3D_TRY(pb3d_scratch(ctx, 15, 64, &f));
         flag = (int*)f;
         PB3D_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
-        int TYL = 32;
-        const i64 tiles = ((D + LT - 1) / LT) * ((W + LT - 1) / LT);
-        while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
-        dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
-        PB3D_REQUIRE(lgrid.y <= 65535u && lgrid.z <= 65535u, "pb3d_rotate_carve: grid too large");
-        if (H >= 32 && W * H * D < (1ll << 32) - 64) {
-            void* cells;
-            PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
-            hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells);
-            PB3D_CHECK_LAUNCH();
-            const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
-            // PB3D_ROTATE_TILE=64 / 128 pins the tile kernel (parity tests run both on the same grids)
-            const char* pin = getenv("PB3D_ROTATE_TILE");
-            const bool wide = pin ? atoi(pin) == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2);
-            if (wide) {
-                static bool attr_set = false;
-                if (!attr_set) {
-                    PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
-                    PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
-                    attr_set = true;
-                }
-                void* trows;
-                PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)xtiles * XQ * sizeof(TileRows), &trows));
-                hipLaunchKernelGGL(k_rot_tile_rows, dim3((unsigned)(xtiles * XQ)), dim3(XTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D,
-                                   (int)((D + XT - 1) / XT), (TileRows*)trows);
-                PB3D_CHECK_LAUNCH();
-                const int TYX = 64;
-                const i64 nblkx = 8 * ((xtiles + 7) / 8) * ((H + TYX - 1) / TYX);
-                PB3D_REQUIRE(nblkx < (1ll << 31), "pb3d_rotate_carve: grid too large");
-                if (D % 16 == 0)
-                    hipLaunchKernelGGL(k_rotate_bits16w<false>, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh,
-                                       (const CellRec*)cells, (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
-                else
-                    hipLaunchKernelGGL(k_rotate_bits16w<true>, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh,
-                                       (const CellRec*)cells, (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
-                PB3D_CHECK_LAUNCH();
-                goto tiled_done;
-            }
-            int TYW = 64;        // multiples of 32 planes per workgroup (measured at 1024^3: 32/64 planes 0.76 ms, 128: 0.79, 256: 0.88)
-            while (TYW > 32 && tiles * ((H + TYW - 1) / TYW) < (i64)ctx->cus * 4) TYW >>= 1;
-            const i64 nblk = 8 * ((tiles + 7) / 8) * ((H + TYW - 1) / TYW);
-            PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
-            if (D % 16 == 0)
-                hipLaunchKernelGGL(k_rotate_bits32<false>, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh,
-                                   (const CellRec*)cells, W, H, D, TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
-            else
-                hipLaunchKernelGGL(k_rotate_bits32<true>, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh,
-                                   (const CellRec*)cells, W, H, D, TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
-        } else if (D % 16 == 0 && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u) == 0)
-            hipLaunchKernelGGL(k_rotate_bits<true>, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
-        else
-            hipLaunchKernelGGL(k_rotate_bits<false>, lgrid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TYL, flag);
-        PB3D_CHECK_LAUNCH();
+        PB3D_TRY(launch_table_step(ctx, d_in, W, H, D, p, d_mask_wh, d_out, flag));
     }
-tiled_done:
     int TY = tiled ? 64 : 16;      // after a table-driven step the grid only reads the flag: keep that launch small
     // keep at least ~8 blocks per CU in flight for small grids
     const i64 tiles_xz = ((D + 255) / 256) * ((W + 3) / 4);
