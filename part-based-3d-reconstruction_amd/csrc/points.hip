@@ -228,6 +228,26 @@ __device__ __forceinline__ u32 select16(const SelParams& p, const u32* htab, con
     return bits;
 }
 
+// occupancy grids (C == 1): the 16 voxels are one 16-byte load; selected = byte != 0
+__device__ __forceinline__ u32 select16_occ(const u8* __restrict__ grid, i64 v0, i64 nvox, u32 w[4]) {
+    if (v0 + 16 <= nvox) {
+        const u32x4v t = *(const u32x4v*)(grid + v0);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u32 t = 0;
+            for (int b = 0; b < 4; ++b) { const i64 o = v0 + 4 * k + b; if (o < nvox) t |= (u32)grid[o] << (8 * b); }
+            w[k] = t;
+        }
+    }
+    u32 bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bits |= (u32)(((w[i >> 2] >> (8 * (i & 3))) & 0xffu) != 0u) << i;
+    return bits;
+}
+
+template <int C>
 __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ grid, SelParams p, u32* __restrict__ block_counts) {
     __shared__ u32 wsum[4];
     __shared__ u32 htab[256];
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ g
     __syncthreads();
     const i64 v0 = (i64)blockIdx.x * kBlockVox + 16 * threadIdx.x;
     u32 w[12];
-    u32 c = v0 < p.nlat ? (u32)__popc(select16(p, htab, grid, v0, p.nlat, w)) : 0u;
+    u32 c = v0 < p.nlat ? (u32)__popc(C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -245,7 +265,8 @@ __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ g
 // Phase 1: every thread ranks its selected voxels inside the block and drops (local index, colour) records into LDS
 // in output order.  Phase 2: the block writes the compacted points and colours; coordinates come from the block's
 // base (a0,a1,a2) plus the local index with exact multiply-high divisions (no integer divide in the loop), colour
-// bytes leave as whole dwords cut out of two neighbouring 24-bit records.
+// bytes leave as whole dwords cut out of two neighbouring 24-bit records (C == 1: four one-byte records per dword).
+template <int C>
 __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
                                                        float* __restrict__ pts, u8* __restrict__ cols) {
     __shared__ u32 wsum[4];
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     const i64 base = (i64)blockIdx.x * kBlockVox;
     const i64 v0 = base + 16 * threadIdx.x;
     u32 w[12];
-    const u32 bits = v0 < p.nlat ? select16(p, htab, grid, v0, p.nlat, w) : 0u;
+    const u32 bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
     const u32 c = (u32)__popc(bits);
     u32 inc = c;
     for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
@@ -272,7 +293,8 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
         if ((bits >> i) & 1u) {
             const int j = (3 * i) >> 2, sh = (3 * i) & 3;
             lidx[k] = (unsigned short)(16 * threadIdx.x + i);
-            lrec[k] = __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) & 0x00ffffffu;
+            lrec[k] = C == 3 ? __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1] : 0u, w[j], (u32)sh) & 0x00ffffffu
+                             : (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
             ++k;
         }
     }
@@ -301,16 +323,20 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
         po[3 * pt] = (float)a2; po[3 * pt + 1] = (float)a1; po[3 * pt + 2] = (float)a0;
     }
     // colours: head bytes up to the first dword boundary of the output, then whole dwords, then the tail
-    u8* co = cols + 3 * out0;
-    const u32 nbytes = 3 * total;
+    u8* co = cols + C * out0;
+    const u32 nbytes = C * total;
     const u32 head = (u32)((4 - ((uintptr_t)co & 3u)) & 3u);
     const u32 hb = head < nbytes ? head : nbytes;
-    auto stream_byte = [&](u32 q) -> u8 { const u32 r = (q * 43691u) >> 17; return (u8)(lrec[r] >> (8 * (q - 3 * r))); };
+    auto stream_byte = [&](u32 q) -> u8 {
+        if (C == 1) return (u8)lrec[q];
+        const u32 r = (q * 43691u) >> 17; return (u8)(lrec[r] >> (8 * (q - 3 * r)));
+    };
     if (threadIdx.x < hb) co[threadIdx.x] = stream_byte(threadIdx.x);
     const u32 ndw = (nbytes - hb) / 4;
     u32* cw = (u32*)(co + hb);
     for (u32 d = threadIdx.x; d < ndw; d += 256) {
         const u32 q = hb + 4 * d;                                   // first stream byte of this dword
+        if (C == 1) { cw[d] = lrec[q] | (lrec[q + 1] << 8) | (lrec[q + 2] << 16) | (lrec[q + 3] << 24); continue; }
         const u32 r = (q * 43691u) >> 17, ph = q - 3 * r;           // q / 3 exactly (q < 2^16)
         const unsigned long long two = (unsigned long long)lrec[r] | ((unsigned long long)lrec[r + 1] << 24);
         cw[d] = (u32)(two >> (8 * ph));
@@ -378,8 +404,9 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
     void *counts, *offsets;
     PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)nb * sizeof(u32), &counts));
     PB3D_TRY(pb3d_scratch(ctx, 9, (size_t)(nb + 1) * sizeof(i64), &offsets));
-    const bool fast16 = stride == 1 && C == 3 && (((uintptr_t)d_grid) & 15u) == 0;
-    if (fast16) hipLaunchKernelGGL(k_points_count16, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
+    const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
+    if (fast16 && C == 3) hipLaunchKernelGGL(k_points_count16<3>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
+    else if (fast16) hipLaunchKernelGGL(k_points_count16<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
     else hipLaunchKernelGGL(k_points_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
     PB3D_CHECK_LAUNCH();
     i64* total = (i64*)offsets + nb;
@@ -416,9 +443,12 @@ int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64
     const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
     PB3D_REQUIRE(ctx->scratch[9] && ctx->scratch_bytes[9] >= (size_t)(nb + 1) * sizeof(i64),
                  "pb3d_points_fill: call pb3d_points_count first");
-    const bool fast16 = stride == 1 && C == 3 && (((uintptr_t)d_grid) & 15u) == 0;
-    if (fast16)
-        hipLaunchKernelGGL(k_points_fill16, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
+    const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
+    if (fast16 && C == 1)
+        hipLaunchKernelGGL(k_points_fill16<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
+                           d_cols);
+    else if (fast16)
+        hipLaunchKernelGGL(k_points_fill16<3>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
                            d_cols);
     else
         hipLaunchKernelGGL(k_points_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,

@@ -81,7 +81,7 @@ def main():
             report("M4", f"one rotate+carve step, {ang} deg", timeit(lambda: dev.rotate_carve(d_occ, S, S, S, M, off, d_mwh, d_o1), a.reps), 2)
     d_occ.free(); d_o1.free(); d_tmp.free()
     d_col = None
-    if any(o in ops for o in ("M5", "M6", "M7", "M8")):
+    if any(o in ops for o in ("M5", "M6", "M7", "M8", "A9")):
         d_col = dev.DeviceBuffer(nvox * 3)
         ms = timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col), a.reps)
         if "M5" in ops:
@@ -103,6 +103,20 @@ def main():
         report("M6", "part_carve, six 90-degree jobs", ms, 36, {"jobs": 6, "ms_per_job": round(ms / 6, 4)})
         for b in (d_ms, d_mc, d_out):
             b.free()
+    if "A9" in ops:
+        # connected components of one part colour on the carved 1024^3 colour grid (left_right_guided_carve / recolor set-up):
+        # label + per-component statistics; labels are int32 (4 B/voxel written), the grid is read once (3 B/voxel)
+        col = np.array(pb3d.PART_COLORS["full_building"], np.uint8)
+        d_lab = dev.DeviceBuffer(nvox * 4)
+        ncomp = C.c_int64(0)
+        lab_fn = lambda: L.check(lib.pb3d_label_color_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, L.p_u8(col), C.c_void_p(d_lab.ptr), C.byref(ncomp)))
+        ms = timeit(lab_fn, 2, warm=1)
+        report("A9", "connected components of one colour (label)", ms, 7, {"components": ncomp.value})
+        nc = max(1, ncomp.value)
+        bbox = (C.c_int64 * (6 * nc))(); cnt = (C.c_int64 * nc)(); csum = (C.c_int64 * (3 * nc))()
+        st_fn = lambda: L.check(lib.pb3d_component_stats_dev(L.ctx(), C.c_void_p(d_lab.ptr), S, S, S, ncomp.value, bbox, cnt, csum))
+        report("A9", "component statistics (bbox, count, coordinate sums)", timeit(st_fn, 2, warm=1), 4)
+        d_lab.free()
     if "M7" in ops or "M8" in ops:
         cols = np.ascontiguousarray(np.array(list(pb3d.PART_COLORS.values()), np.uint8))
         n = C.c_int64(0)
