@@ -50,32 +50,56 @@ __device__ __forceinline__ bool is_color(const u8* __restrict__ g, i64 v, u8 r, 
     return g[3 * v] == r && g[3 * v + 1] == gg && g[3 * v + 2] == b;
 }
 
-__global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 n, u8 r, u8 g, u8 b, int* __restrict__ parent,
+// parent[v] = first voxel of v's run of members along the fastest axis, cut at row starts and at the 64-voxel segments a
+// wavefront covers (ballot arithmetic, no atomics): the a2-links inside a segment are never made one by one.
+__global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 n, i64 A2, u8 r, u8 g, u8 b, int* __restrict__ parent,
                                                   u8* __restrict__ member) {
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (i64)gridDim.x * blockDim.x) {
-        parent[v] = (int)v;
-        member[v] = is_color(grid, v, r, g, b) ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 nloop = (n + stride - 1) / stride;               // same trip count for every lane: ballots stay convergent
+    for (i64 it = 0; it < nloop; ++it) {
+        const i64 v = it * stride + (i64)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool m = v < n && is_color(grid, v, r, g, b);
+        const u64 bal = __ballot(m);
+        const bool prev = lane > 0 && ((bal >> (lane - 1)) & 1ull);
+        const bool start = m && (!prev || v % A2 == 0);
+        const u64 starts = __ballot(start);
+        if (v < n) {
+            int par = (int)v;
+            if (m) {
+                const u64 upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                par = (int)(v - (lane - (63 - __clzll((long long)upto))));
+            }
+            parent[v] = par;
+            member[v] = m ? 1 : 0;
+        }
     }
 }
 
+// Links across the three axes.  A link (v, v+s) is skipped when the pair one step back along the fastest axis, (v-1, v-1+s),
+// exists in the same row: it connects the same two runs (runs are already linked inside by k_ccl_init / the a2-links), so for
+// blob-like components the atomics drop from one per face to one per run pair.
 __global__ __launch_bounds__(256) void k_ccl_merge(const u8* __restrict__ member, i64 A0, i64 A1, i64 A2, int* parent) {
     const i64 n = A0 * A1 * A2;
     for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (i64)gridDim.x * blockDim.x) {
         if (!member[v]) continue;
         const i64 a2 = v % A2, r = v / A2, a1 = r % A1, a0 = r / A1;
-        if (a2 + 1 < A2 && member[v + 1]) uf_union(parent, (int)v, (int)(v + 1));
-        if (a1 + 1 < A1 && member[v + A2]) uf_union(parent, (int)v, (int)(v + A2));
-        if (a0 + 1 < A0 && member[v + A1 * A2]) uf_union(parent, (int)v, (int)(v + A1 * A2));
+        const bool back = a2 > 0 && member[v - 1];
+        if (a2 + 1 < A2 && (v & 63) == 63 && member[v + 1]) uf_union(parent, (int)v, (int)(v + 1));   // only across init's segments
+        if (a1 + 1 < A1 && member[v + A2] && !(back && member[v + A2 - 1])) uf_union(parent, (int)v, (int)(v + A2));
+        if (a0 + 1 < A0 && member[v + A1 * A2] && !(back && member[v + A1 * A2 - 1])) uf_union(parent, (int)v, (int)(v + A1 * A2));
     }
 }
 
 // parent[v] <- root(v) for members; rootflag[v] = 1 at roots
-__global__ __launch_bounds__(256) void k_ccl_flatten(u8* __restrict__ member_to_rootflag, i64 n, const int* parent, int* __restrict__ root_out) {
+__global__ __launch_bounds__(256) void k_ccl_flatten(u8* __restrict__ member_to_rootflag, i64 n, const int* parent, int* __restrict__ root_out,
+                                                     u8* __restrict__ rootimg) {
     for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (i64)gridDim.x * blockDim.x) {
-        if (!member_to_rootflag[v]) { root_out[v] = -1; continue; }
+        if (!member_to_rootflag[v]) { root_out[v] = -1; rootimg[v] = 0; continue; }
         const int root = uf_find(const_cast<int*>(parent), (int)v);
         root_out[v] = root;                                  // written to a separate array: parent[] stays intact for the other finds
         member_to_rootflag[v] = (root == (int)v) ? 1 : 2;   // 1 = root, 2 = member
+        rootimg[v] = (root == (int)v) ? 1 : 0;              // the image the ordered compaction of the roots reads
     }
 }
 
@@ -286,8 +310,6 @@ __global__ __launch_bounds__(256) void k_orient(const u8* __restrict__ grid, u8*
 
 }  // namespace
 
-int pb3d_keep_only_ones(pb3d_ctx* ctx, u8* d_img, i64 n);
-
 extern "C" {
 
 int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
@@ -302,25 +324,21 @@ int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, i
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)n * sizeof(int), &parent));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)n, &flag));
     const unsigned blocks = pb3d_stream_blocks(ctx, n, 256, 8);
-    hipLaunchKernelGGL(k_ccl_init, dim3(blocks), dim3(256), 0, ctx->stream, d_grid_rgb, n, color[0], color[1], color[2], (int*)parent,
+    hipLaunchKernelGGL(k_ccl_init, dim3(blocks), dim3(256), 0, ctx->stream, d_grid_rgb, n, A2, color[0], color[1], color[2], (int*)parent,
                        (u8*)flag);
     PB3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ccl_merge, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)flag, A0, A1, A2, (int*)parent);
     PB3D_CHECK_LAUNCH();
-    void* roots;
+    // flag values after the flatten: 0 none, 1 root, 2 member; rootimg holds the roots only (what the ordered compaction selects)
+    void *roots, *rootimg;
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)n * sizeof(int), &roots));
-    hipLaunchKernelGGL(k_ccl_flatten, dim3(blocks), dim3(256), 0, ctx->stream, (u8*)flag, n, (const int*)parent, (int*)roots);
-    PB3D_CHECK_LAUNCH();
-    // roots in raster order: ordered compaction of (flag == 1)
-    // flag values: 0 none, 1 root, 2 member; the compaction selects non-zero bytes, so it gets a copy holding the roots only
-    void* rootimg;
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)n, &rootimg));
-    PB3D_HIP(hipMemcpyAsync(rootimg, flag, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-    PB3D_TRY(pb3d_keep_only_ones(ctx, (u8*)rootimg, n));
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(blocks), dim3(256), 0, ctx->stream, (u8*)flag, n, (const int*)parent, (int*)roots, (u8*)rootimg);
+    PB3D_CHECK_LAUNCH();
     i64 nroots = 0;
     PB3D_TRY(pb3d_points_count_dev(ctx, (const u8*)rootimg, A0, A1, A2, 1, nullptr, 0, 1, &nroots));
-    PB3D_HIP(hipMemsetAsync(d_labels, 0, (size_t)n * sizeof(int), ctx->stream));
-    if (nroots > 0) {
+    if (nroots == 0) PB3D_HIP(hipMemsetAsync(d_labels, 0, (size_t)n * sizeof(int), ctx->stream));
+    if (nroots > 0) {      // every entry of d_labels is written: roots by k_ccl_rank, members and non-members by k_ccl_relabel
         void *pts, *cols;
         PB3D_TRY(pb3d_scratch(ctx, 13, (size_t)nroots * 3 * sizeof(float), &pts));
         PB3D_TRY(pb3d_scratch(ctx, 14, (size_t)nroots, &cols));
@@ -450,16 +468,3 @@ int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_
 }
 
 }  // extern "C"
-
-namespace {
-__global__ __launch_bounds__(256) void k_keep_only_ones(u8* __restrict__ img, i64 n) {
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (i64)gridDim.x * blockDim.x)
-        if (img[v] != 1) img[v] = 0;
-}
-}  // namespace
-
-int pb3d_keep_only_ones(pb3d_ctx* ctx, u8* d_img, i64 n) {
-    hipLaunchKernelGGL(k_keep_only_ones, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_img, n);
-    PB3D_CHECK_LAUNCH();
-    return PB3D_OK;
-}
