@@ -31,6 +31,39 @@ def equal_slabs(n_planes, nranks):
     return n_planes // nranks
 
 
+# ---- Y-slab partition (SURVEY.md 8(e), first row) -----------------------------------------------------------------------
+# Every carve op of the path is independent per Y-plane: the rotation is about Y, masks broadcast along Z, colours and part
+# selection are per (x,y) column.  A rank that holds the (W, H_r, D) sub-volume of the planes y0..y1 and the rows y0..y1
+# of the (H,W) images therefore runs the SAME entry points (carve_voxel_grid_with_masks, process_voxel_grid with any angle
+# and any number of chained steps, global_carve, part_carve, apply_colored_mask_to_voxel_grid, extrude_from_surface) on
+# its slab with no communication at all; the full volume is the concatenation of the slabs along axis 1.  (Connected
+# components cross planes and do not shard this way.  part_carve on a grid with W == H inherits the reference's square-mask
+# quirk -- _mask_to_wh transposes the part mask a second time -- which a slab with H_r != W does not reproduce: partition
+# part_carve by Y on non-square grids, as the reference's own (w, h, w) grids with h != w are.)
+def y_slab_bounds(n_rows, rank, nranks):
+    """[y0, y1) of rank's share of the H image rows / grid planes (same dealing rule as slab_bounds)."""
+    return slab_bounds(n_rows, rank, nranks)
+
+
+def y_slab_image(image_hw, rank, nranks):
+    """Rows y0..y1 of an (H,W) or (H,W,3) image -- the mask this rank passes with its (W, y1-y0, D) sub-volume."""
+    a = np.asarray(image_hw)
+    y0, y1 = y_slab_bounds(a.shape[0], rank, nranks)
+    return np.ascontiguousarray(a[y0:y1])
+
+
+def y_slab_grid(grid_whd, rank, nranks):
+    """Planes y0..y1 (axis 1) of a (W,H,D[,3]) grid as a contiguous sub-volume."""
+    g = np.asarray(grid_whd)
+    y0, y1 = y_slab_bounds(g.shape[1], rank, nranks)
+    return np.ascontiguousarray(g[:, y0:y1])
+
+
+def assemble_y_slabs(slabs):
+    """Full (W,H,D[,3]) volume from the ranks' sub-volumes, in rank order."""
+    return np.concatenate([np.asarray(s) for s in slabs], axis=1)
+
+
 def new_unique_id():
     uid = np.zeros(128, np.uint8)
     _lib.check(_lib.load().pb3d_comm_unique_id(_lib.p_u8(uid)))

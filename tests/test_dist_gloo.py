@@ -72,13 +72,33 @@ def _worker(rank, world, port, q):
         tk = torch.from_numpy(keys)
         dist.all_reduce(tk, op=dist.ReduceOp.MAX)
         ok_e = np.array_equal(resolve_keys(tk.numpy().astype(np.uint64)), want)
+        # (f) Y-slab partition (planes are independent: rotation about Y, masks per (x,y)): a chained 45-degree
+        #     process_voxel_grid, global_carve and part_carve run per rank on its planes with its mask rows, no exchange;
+        #     one all_gather of the (equal) sub-volumes, concatenated along axis 1 == the unsharded result
+        from pb3d.dist import y_slab_image, y_slab_grid, assemble_y_slabs
+
+        def gathered(mine):
+            parts = [torch.empty_like(torch.from_numpy(mine)) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(mine)))
+            return assemble_y_slabs([p.numpy() for p in parts])
+        occ = synth_host.occ_slab(0, S, S, S, seed=3)
+        ok_f = np.array_equal(gathered(orc.process_voxel_grid(y_slab_grid(occ, rank, world), y_slab_image(binary, rank, world), 45)),
+                              orc.process_voxel_grid(occ, binary, 45))
+        ok_f = ok_f and np.array_equal(gathered(orc.global_carve(y_slab_image(binary, rank, world), y_slab_image(rgb, rank, world), 90)), g_full)
+        # part_carve on a NON-square grid (W = 32, H = 24): with W == H the reference's _mask_to_wh transposes the already
+        # transposed part mask once more (a quirk pb3d mirrors), which a slab with H_r != W cannot reproduce
+        jobs = [(["full_building"], 90), (["chhatris", "plinth"], 45)]
+        bin24, rgb24 = np.ascontiguousarray(binary[4:28]), np.ascontiguousarray(rgb[4:28])
+        g24 = orc.global_carve(bin24, rgb24, 90)                                    # (32, 24, 32, 3)
+        ok_f = ok_f and np.array_equal(gathered(orc.part_carve(y_slab_grid(g24, rank, world), y_slab_image(rgb24, rank, world), jobs)),
+                                       orc.part_carve(g24, rgb24, jobs))
         # (d) max-over-ranks timing reduction used by bench.py
         t = torch.tensor([0.25 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ok_d = float(t) == 0.25 + world - 1
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, ok_a, ok_b, ok_c, ok_d and ok_e))
+        q.put((rank, ok_a, ok_b, ok_c, ok_d and ok_e and ok_f))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "error", traceback.format_exc(), str(e), None))

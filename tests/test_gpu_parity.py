@@ -676,3 +676,27 @@ def test_full_size_process_grid_45_against_oracle_slab(pb3d_gpu, oracle):
         assert np.array_equal(full[:, ys, :], want), y0
     for b in (d_occ, d_out, d_tmp, d_out64, d_mwh):
         b.free()
+
+
+@pytest.mark.gpu
+def test_y_slab_partition_gpu(pb3d_gpu, golden):
+    """SURVEY 8(e) first row on the device path: an uneven 3-way Y-slab partition (18 | 17 | 17 planes of the real Taj masks
+    at max_dim 96: a 95 x 52 x 95 grid) of global_carve, a chained 45-degree process_voxel_grid and the notebook-1 part_carve jobs,
+    each rank's slab computed on its own with its mask rows, equals the unsharded result after concatenation."""
+    from pb3d import dist
+    g = golden("f4_Taj_96")
+    ext, binary = g["ext"], g["binary"]
+    H = binary.shape[0]
+    full_gc = pb3d_gpu.global_carve(binary, ext, angle_interval=90)
+    assert full_gc.shape[1] == H and full_gc.shape[0] != H            # (w, h, w, 3), non-square
+    nr = 3
+    parts = [pb3d_gpu.global_carve(dist.y_slab_image(binary, r, nr), dist.y_slab_image(ext, r, nr), angle_interval=90) for r in range(nr)]
+    assert np.array_equal(dist.assemble_y_slabs(parts), full_gc)
+    occ = (full_gc.any(-1)).astype(np.uint8)
+    full_p = pb3d_gpu.process_voxel_grid(occ, binary, 45)
+    parts = [pb3d_gpu.process_voxel_grid(dist.y_slab_grid(occ, r, nr), dist.y_slab_image(binary, r, nr), 45) for r in range(nr)]
+    assert np.array_equal(dist.assemble_y_slabs(parts), full_p)
+    for jobs in (JOBS_NB1, JOBS_MIXED):
+        full_pc = pb3d_gpu.part_carve(full_gc, ext, jobs)
+        parts = [pb3d_gpu.part_carve(dist.y_slab_grid(full_gc, r, nr), dist.y_slab_image(ext, r, nr), jobs) for r in range(nr)]
+        assert np.array_equal(dist.assemble_y_slabs(parts), full_pc)
