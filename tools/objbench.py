@@ -1,0 +1,30 @@
+"""Latency of one camera-objective evaluation (row N4: project + per-part IoU on the resident cloud) on the stored monuments.
+python tools/objbench.py"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "part-based-3d-reconstruction_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import pb3d  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+meta = json.load(open(os.path.join(GOLDEN, "n45_objective_zbuffer.json")))
+for mon in ("Akbar", "Charminar"):
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    m = meta[f"objective_{mon}"]
+    PC = pb3d.PART_COLORS
+    front = np.load(os.path.join(GOLDEN, "f7_projection.npz"))[f"img_{mon}_front"]
+    seg = pb3d.mask_parts_from_image(front, PC, m["parts"])
+    pts, cols = pb3d.get_voxel_points_by_parts(grid, PC, m["parts"])
+    obj = pb3d.CameraObjective(pts, cols, seg, {p: PC[p] for p in m["parts"]})
+    t = m["trials"][0]
+    prm = {"cam_pos": np.array(t["cam_pos"]), "target": np.array(t["target"]), "f": t["f"], "cx": t["cx"], "cy": t["cy"], "H": m["H"], "W": m["W"]}
+    for _ in range(20):
+        obj(prm)
+    n = 500
+    t0 = time.perf_counter()
+    for _ in range(n):
+        obj(prm)
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"monument": mon, "points": int(len(pts)), "image": [m["H"], m["W"]], "parts": len(m["parts"]),
+                      "us_per_evaluation": round(dt * 1e6, 1), "evaluations_per_s": round(1 / dt)}), flush=True)
+    obj.close()
