@@ -49,7 +49,7 @@ __device__ __forceinline__ void store48_wave(u32x4_u* __restrict__ out, i64 gw0,
 // each lane looks up its column's keep byte and a wave64 ballot turns the 64 decisions into one
 // scalar word: all-drop wavefronts issue no load at all, all-keep wavefronts load unpredicated.
 // Dropped columns are never read -- only zeros are stored.  Many small tiles and at most two loads
-// per lane measured fastest on MI355X (profiles/r01_k1_variants.md): the hardware dispatcher
+// per lane measured fastest on MI355X (profiles/r01_k1_variants_run*.txt): the hardware dispatcher
 // balances the stream better than a persistent grid-stride loop.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileVec = 768;
