@@ -892,7 +892,7 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         const int TYX = 64;
         const i64 nblkx = 8 * ((xtiles + 7) / 8) * ((H + TYX - 1) / TYX);
         PB3D_REQUIRE(nblkx < (1ll << 31), "pb3d_rotate_carve: grid too large");
-        auto kern = D % 16 == 0 ? k_rotate_bits16w<false> : k_rotate_bits16w<true>;
+        auto kern = D % XCELLS == 0 ? k_rotate_bits16w<false> : k_rotate_bits16w<true>;     // a thread's run is XCELLS = 32 voxels
         hipLaunchKernelGGL(kern, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh, (const CellRec*)cells,
                            (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
     } else {

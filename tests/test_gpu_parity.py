@@ -515,7 +515,9 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
     # (160,90,160) / (176,64,192): 32-plane bit-sliced kernel (ragged / whole passes); (200,60,180) / (131,128,130) /
     # (133,121,129): the same kernel with rows at arbitrary byte alignment and ragged row ends; (400,20,272) / (300,20,357):
     # fewer than 32 planes -> 8-plane kernel, aligned and byte-wise forms
-    for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130), (133, 121, 129), (300, 20, 357)]:
+    # (271,33,240): D % 16 == 0 but D % 32 != 0 -- the wide kernel's 32-voxel runs straddle the row end (found by tools/fuzz_gpu.py)
+    for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130), (133, 121, 129), (300, 20, 357),
+                      (271, 33, 240)]:
         m = rng.random((H, W)) < 0.9
         g_bin = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         g_full = rng.integers(0, 256, (W, H, D), dtype=np.uint8)

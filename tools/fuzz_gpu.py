@@ -1,0 +1,74 @@
+"""Long randomised GPU-vs-oracle sweep (development tool, not part of the test suite): python tools/fuzz_gpu.py [seconds] [seed].
+Covers carve, colour apply, occupancy, process_voxel_grid (both generic-angle tile kernels pinned in turn), part_carve,
+global_carve, point extraction and projection on random shapes (odd / aligned / ragged), densities and dtypes."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "part-based-3d-reconstruction_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import pb3d  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
+    pal = np.array(list(oracle.PART_COLORS.values()), np.uint8)
+    names = list(oracle.PART_COLORS)
+    t0 = time.time(); n = 0; counts = {}
+    def ok(tag, a, b, info):
+        counts[tag] = counts.get(tag, 0) + 1
+        if not np.array_equal(a, b):
+            print("MISMATCH", tag, info, flush=True); sys.exit(1)
+    while time.time() - t0 < budget:
+        n += 1
+        big = n % 7 == 0 or os.environ.get("FUZZ_BIG") == "1"      # FUZZ_BIG=1: every case large enough for the tiled kernels
+        lo = 120 if os.environ.get("FUZZ_BIG") == "1" else 1
+        W = int(rng.integers(lo, 300 if big else 100)); H = int(rng.integers(max(1, lo // 3), 70 if big else 40)); D = int(rng.integers(lo, 300 if big else 100))
+        r = n % 5
+        if r == 0: D = W
+        if r == 1: W = D = int(rng.choice([16, 32, 48, 64, 96, 128, 160, 256]))
+        if r == 2: D = W + 2 * int(rng.integers(-10, 10)); D = max(1, D)
+        ai = int(rng.choice([90, 90, 60, 45, 30, 20, 10, 120, 7]))
+        dens = rng.uniform(0.05, 0.95)
+        g = (rng.random((W, H, D)) < dens).astype(np.uint8) if n % 6 else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+        m = rng.random((H, W)) < rng.uniform(0.2, 1.0)
+        info = (n, W, H, D, ai)
+        want = oracle.process_voxel_grid(g, m, ai)
+        for tile in ("64", "128", None):
+            if tile: os.environ["PB3D_ROTATE_TILE"] = tile
+            else: os.environ.pop("PB3D_ROTATE_TILE", None)
+            ok("process", pb3d.process_voxel_grid(g, m, ai), want, info + (tile,))
+        os.environ.pop("PB3D_ROTATE_TILE", None)
+        col = pal[rng.integers(0, len(pal), (W, H, D))] * (rng.random((W, H, D, 1)) < dens).astype(np.uint8)
+        ok("carve_rgb", pb3d.carve_voxel_grid_with_masks(col, m), oracle.carve_voxel_grid_with_masks(col, m), info)
+        ok("carve_occ", pb3d.carve_voxel_grid_with_masks(g, m), oracle.carve_voxel_grid_with_masks(g, m), info)
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        c3 = rng.integers(0, 3, (W, H, D), dtype=np.uint8)
+        ok("color_apply", pb3d.apply_colored_mask_to_voxel_grid(c3, rgb), oracle.apply_colored_mask_to_voxel_grid(c3, rgb), info)
+        sem = pal[rng.integers(0, len(pal), (H // 3 + 1, W // 3 + 1))].repeat(3, 0).repeat(3, 1)[:H, :W]
+        jobs = [([names[int(rng.integers(0, len(names)))], names[int(rng.integers(0, len(names)))]], int(rng.choice([90, 90, 45, 30]))) for _ in range(int(rng.integers(1, 5)))]
+        ok("part_carve", pb3d.part_carve(col, sem, jobs), oracle.part_carve(col, sem, jobs), info + (jobs,))
+        binary = (~np.all(sem == pal[9], axis=-1)).astype(np.uint8)
+        ga = int(rng.choice([90, 90, 45]))
+        ok("global_carve", pb3d.global_carve(binary, sem, ga), oracle.global_carve(binary, sem, ga), info + (ga,))
+        sel = [names[i] for i in rng.choice(len(names), int(rng.integers(1, len(names))), replace=False)]
+        gp, gc = pb3d.get_voxel_points_by_parts(col, oracle.PART_COLORS, sel)
+        op, oc = oracle.get_voxel_points_by_parts(col, oracle.PART_COLORS, sel)
+        ok("points", gp, op, info); ok("points_cols", gc, oc, info)
+        st = int(rng.choice([1, 1, 2, 3]))
+        a = pb3d.voxel_grid_to_points(g, stride=st) if False else None
+        if len(gp):
+            f64 = n % 3 == 0
+            cam = np.array([W / 2 + rng.normal(), H / 2 + rng.normal(), -2.5 * max(W, D)], np.float64 if f64 else np.float32)
+            tgt = np.array([W / 2, H / 2, D / 2], cam.dtype)
+            args = (cam, tgt, float(1.2 * max(W, H)), W / 2.0, H / 2.0, int(H + 3), int(W + 5))
+            with np.errstate(all="ignore"):
+                ok("project", pb3d.project_colored_voxels(gp, gc, *args), oracle.project_colored_voxels(gp, gc, *args), info + (f64,))
+    print(json.dumps({"seed": seed, "cases": n, "seconds": round(time.time() - t0, 1), "checks": counts}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
