@@ -67,6 +67,56 @@ def main():
             args = (cam, tgt, float(1.2 * max(W, H)), W / 2.0, H / 2.0, int(H + 3), int(W + 5))
             with np.errstate(all="ignore"):
                 ok("project", pb3d.project_colored_voxels(gp, gc, *args), oracle.project_colored_voxels(gp, gc, *args), info + (f64,))
+        if os.environ.get("FUZZ_COMPONENTS", "1") == "1" and n % 3 == 0 and W * H * D <= 400000:
+            import contextlib, io
+            # blob-like colour grid: a few boxes per part colour -> several 3-D components per colour
+            cg = np.zeros((W, H, D, 3), np.uint8)
+            for _ in range(int(rng.integers(1, 9))):
+                lo = [int(rng.integers(0, s)) for s in (W, H, D)]
+                hi = [min(s, l + int(rng.integers(1, max(2, s // 2)))) for s, l in zip((W, H, D), lo)]
+                cg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = pal[int(rng.integers(0, 4))]
+            cg[rng.random((W, H, D)) < 0.02] = 0
+            tc = tuple(int(v) for v in pal[int(rng.integers(0, 4))])
+            ang = int(rng.choice([60, 90, 45]))
+            b1, b2 = io.StringIO(), io.StringIO()
+            with contextlib.redirect_stdout(b1):
+                a = pb3d.left_right_guided_carve(cg, sem, tc, angle=ang)
+            with contextlib.redirect_stdout(b2):
+                b = oracle.left_right_guided_carve(cg, sem, tc, angle=ang)
+            ok("lrgc", a, b, info + (tc, ang))
+            if b1.getvalue() != b2.getvalue():
+                print("MISMATCH lrgc log", info, flush=True); sys.exit(1)
+            k = int(rng.integers(0, 5)); sa = int(rng.integers(0, 3)); nc = tuple(int(v) for v in pal[5])
+            ok("recolor", pb3d.recolor_backward_components(cg, tc, nc, k=k, sort_axis=sa), oracle.recolor_backward_components(cg, tc, nc, k=k, sort_axis=sa), info + (k, sa))
+            for axis in (2, 0):
+                m2 = rng.random((H, W)) < 0.7
+                if axis == 0 and W != D:
+                    continue                                   # the reference indexes the (H,W) mask with (y,z) on axis 0: needs W == D
+                dirn = "+" if rng.random() < 0.5 else "-"; dep = int(rng.integers(0, 6))
+                fc = None if rng.random() < 0.5 else tuple(int(v) for v in pal[6])
+                ok("extrude", pb3d.extrude_from_surface(cg, m2, axis, direction=dirn, depth=dep, fill_color=fc),
+                   oracle.extrude_from_surface(cg, m2, axis, direction=dirn, depth=dep, fill_color=fc), info + (axis, dirn, dep, fc))
+            # z-buffer and visibility (float32 / float64 cameras)
+            for f64 in (False, True):
+                dt = np.float64 if f64 else np.float32
+                camd = {"cam_pos": np.array([W / 2, H / 2, -2.0 * max(W, D)], dt), "target": np.array([W / 2, H / 2, D / 2], dt),
+                        "f": float(1.1 * max(W, H)), "cx": W / 2.0, "cy": H / 2.0}
+                Hh, Ww = H + 2, W + 3
+                with np.errstate(all="ignore"):
+                    zg = pb3d.compute_global_depth_buffer(cg, camd, Hh, Ww); zo = oracle.compute_global_depth_buffer(cg, camd, Hh, Ww)
+                    ok("zbuf", zg, zo, info + (f64,))
+                    pp, _ = oracle.get_voxel_points_by_parts(cg, {"t": tc}, ["t"])
+                    if len(pp):
+                        ok("visible", pb3d.project_part_visible(pp, camd, zo, Hh, Ww), oracle.project_part_visible(pp, camd, zo, Hh, Ww), info + (f64,))
+            img_a = pal[rng.integers(0, 6, (H, W))]; img_b = pal[rng.integers(0, 6, (H, W))]
+            pcs = {names[i]: oracle.PART_COLORS[names[i]] for i in range(6)}
+            ia, ib = pb3d.compute_partwise_iou(img_a, img_b, pcs), oracle.compute_partwise_iou(img_a, img_b, pcs)
+            if repr(ia) != repr(ib):
+                print("MISMATCH iou", info, ia, ib, flush=True); sys.exit(1)
+            counts["iou"] = counts.get("iou", 0) + 1
+            for st in (1, 2, 3):
+                gp2, gc2, _ = pb3d.voxel_grid_to_points(cg, stride=st); op2, oc2, _ = oracle.voxel_grid_to_points(cg, stride=st)
+                ok("grid_to_points", gp2, op2, info + (st,)); ok("grid_to_points_cols", gc2, oc2, info + (st,))
     print(json.dumps({"seed": seed, "cases": n, "seconds": round(time.time() - t0, 1), "checks": counts}), flush=True)
 
 
