@@ -114,6 +114,25 @@ def main():
             if repr(ia) != repr(ib):
                 print("MISMATCH iou", info, ia, ib, flush=True); sys.exit(1)
             counts["iou"] = counts.get("iou", 0) + 1
+            # notebook-3 deformation of one part: coordinates + colours, projection IoU, deformed grid
+            plabels = {names[i]: tuple(int(v) for v in pal[i]) for i in range(4)}
+            part = names[int(rng.integers(0, 4))]
+            dfm = {"scale_xz": float(rng.uniform(0.6, 1.5)), "scale_y": float(rng.uniform(0.6, 1.5)), "shift_xz": float(rng.uniform(-20, 20)),
+                   "shift_y": float(rng.uniform(-20, 20))}
+            ishape = (int(rng.integers(20, 200)), int(rng.integers(20, 200)))
+            ca, cca = pb3d.deform_part(cg, plabels, part, dfm, ishape); cb, ccb = oracle.deform_part(cg, plabels, part, dfm, ishape)
+            ok("deform_coords", ca, cb, info + (part, dfm, ishape)); ok("deform_colors", cca, ccb, info)
+            imgd = pal[rng.integers(0, 4, ishape)]
+            camp = {"cam_pos": np.array([D / 2, H / 2, -2.0 * max(W, D)], np.float32), "target": np.array([D / 2, H / 2, W / 2], np.float32),
+                    "f": float(1.1 * max(ishape)), "cx": ishape[1] / 2.0, "cy": ishape[0] / 2.0}
+            with np.errstate(all="ignore"):
+                pa, ia2 = pb3d.evaluate_part_deform(cg, plabels, part, dfm, imgd, camp); pb_, ib2 = oracle.evaluate_part_deform(cg, plabels, part, dfm, imgd, camp)
+            ok("deform_projection", pa, pb_, info)
+            if ia2 != ib2:
+                print("MISMATCH deform iou", info, ia2, ib2, flush=True); sys.exit(1)
+            saved = {p_: {"deform": {"scale_xz": float(rng.uniform(0.7, 1.3)), "scale_y": float(rng.uniform(0.7, 1.3)), "shift_xz": float(rng.uniform(-10, 10)),
+                                      "shift_y": float(rng.uniform(-10, 10))}} for p_ in list(plabels)[:int(rng.integers(1, 5))]}
+            ok("deformed_grid", pb3d.build_deformed_grid(cg, plabels, saved, ishape), oracle.build_deformed_grid(cg, plabels, saved, ishape), info)
             for st in (1, 2, 3):
                 gp2, gc2, _ = pb3d.voxel_grid_to_points(cg, stride=st); op2, oc2, _ = oracle.voxel_grid_to_points(cg, stride=st)
                 ok("grid_to_points", gp2, op2, info + (st,)); ok("grid_to_points_cols", gc2, oc2, info + (st,))
