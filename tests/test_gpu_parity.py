@@ -702,3 +702,34 @@ def test_y_slab_partition_gpu(pb3d_gpu, golden):
         full_pc = pb3d_gpu.part_carve(full_gc, ext, jobs)
         parts = [pb3d_gpu.part_carve(dist.y_slab_grid(full_gc, r, nr), dist.y_slab_image(ext, r, nr), jobs) for r in range(nr)]
         assert np.array_equal(dist.assemble_y_slabs(parts), full_pc)
+
+
+@pytest.mark.gpu
+def test_large_odd_grid_against_oracle_slabs(pb3d_gpu, oracle):
+    """a 1001 x 720 x 1001 grid (2.16 GB of RGB: byte offsets beyond 2^31, rows of 1001 bytes at every alignment, ragged
+    tiles on all sides) through global_carve, part_carve, a chained 45-degree process_voxel_grid and the mask carve.
+    Y-planes are independent, so slabs of planes of the full results must equal the oracle run on those slabs alone."""
+    rng = np.random.default_rng(77)
+    W, H = 1001, 720
+    PC = oracle.PART_COLORS
+    names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
+    pal = np.array([PC[n] for n in names] + [(0, 0, 0)], np.uint8)
+    sem = pal[rng.integers(0, len(pal), (H // 8 + 1, W // 8 + 1))].repeat(8, 0).repeat(8, 1)[:H, :W]        # blocky part image
+    binary = sem.any(-1).astype(np.uint8)
+    slabs = [(0, 2), (H // 2 - 1, H // 2 + 1), (H - 2, H)]
+    gc = pb3d_gpu.global_carve(binary, sem, angle_interval=90)
+    assert gc.shape == (W, H, W, 3) and gc.nbytes > 2 ** 31
+    for y0, y1 in slabs:
+        assert np.array_equal(gc[:, y0:y1], oracle.global_carve(binary[y0:y1], sem[y0:y1], 90)), ("global_carve", y0)
+    pc = pb3d_gpu.part_carve(gc, sem, JOBS_NB1)
+    for y0, y1 in slabs:
+        assert np.array_equal(pc[:, y0:y1], oracle.part_carve(np.ascontiguousarray(gc[:, y0:y1]), sem[y0:y1], JOBS_NB1)), ("part_carve", y0)
+    m = rng.random((H, W)) < 0.8
+    cv = pb3d_gpu.carve_voxel_grid_with_masks(gc, m)
+    assert np.array_equal(cv[::97], np.where(m.T[::97, :, None, None], gc[::97], 0))
+    del pc, cv
+    occ = np.ascontiguousarray(gc.any(-1)).view(np.uint8)
+    del gc
+    pv = pb3d_gpu.process_voxel_grid(occ, binary, 45)
+    for y0, y1 in slabs:
+        assert np.array_equal(pv[:, y0:y1], oracle.process_voxel_grid(np.ascontiguousarray(occ[:, y0:y1]), binary[y0:y1], 45)), ("process45", y0)
