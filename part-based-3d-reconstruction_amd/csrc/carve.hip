@@ -4,6 +4,7 @@
 // one (x,y) column are contiguous and column index xy = x*H + y also indexes the (W,H) mask.
 // Every kernel here is a coalesced 16-byte-per-lane sweep; none has a contraction (no MFMA).
 #include "pb3d_internal.h"
+#include <vector>
 
 namespace {
 
@@ -418,6 +419,34 @@ __global__ __launch_bounds__(256) void k_part_final16(const u32x4* __restrict__ 
     }
 }
 
+// out[v] = colored[v] where keep[v] (the rest of `out` -- the overlay of the fused 90-degree jobs -- stays)
+__global__ __launch_bounds__(256) void k_part_merge(const u8* __restrict__ colored, const u8* __restrict__ keep, u8* __restrict__ out, i64 nvox) {
+    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x)
+        if (keep[v]) { out[3 * v] = colored[3 * v]; out[3 * v + 1] = colored[3 * v + 1]; out[3 * v + 2] = colored[3 * v + 2]; }
+}
+
+__global__ __launch_bounds__(256) void k_part_merge16(const u32x4* __restrict__ colored, const u32x4* __restrict__ keep, u32x4* __restrict__ out,
+                                                      i64 ngroups) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        const u32x4 kv = ld_nt(keep + g);
+        const u32 kw[4] = {kv.x, kv.y, kv.z, kv.w};
+        u32 keep16 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep16 |= (byte_of(kw, i) ? 1u : 0u) << i;
+        if (!keep16) continue;                               // untouched groups cost 16 bytes of keep
+        u32 m[12];
+        expand16(keep16, 0xffu, 0xffu, 0xffu, m);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const u32x4 c = ld_s(colored + 3 * g + k), o = ld_s(out + 3 * g + k);
+            u32x4 r;
+            r.x = (c.x & m[4 * k]) | (o.x & ~m[4 * k]); r.y = (c.y & m[4 * k + 1]) | (o.y & ~m[4 * k + 1]);
+            r.z = (c.z & m[4 * k + 2]) | (o.z & ~m[4 * k + 2]); r.w = (c.w & m[4 * k + 3]) | (o.w & ~m[4 * k + 3]);
+            st_s(out + 3 * g + k, r);
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
@@ -509,10 +538,25 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
                  "pb3d_part_carve: null buffer");
     for (int j = 0; j < njobs; ++j)
         PB3D_REQUIRE(job_skip[j] || job_angle[j] > 0, "pb3d_part_carve: job %d has angle %d (must be > 0)", j, job_angle[j]);
-    {   // all jobs 90 degrees on a grid the tiled transpose handles: one fused sweep (csrc/rotate_tiled.hip, K5)
-        const int rc = pb3d_try_part_carve90(ctx, d_colored, W, H, D, d_mask_sub, d_mask_carve, job_angle, job_skip, njobs, d_out);
-        if (rc != PB3D_EUNSUPPORTED) return rc;
+    // Every job overlays colored[v] where it keeps, so the result is the union of the jobs' keep sets in any order: all
+    // 90-degree jobs go through ONE fused sweep (csrc/rotate_tiled.hip, K5); jobs with other angles follow one by one and are
+    // merged into that overlay.
+    int n90 = 0, nother = 0;
+    for (int j = 0; j < njobs; ++j)
+        if (!job_skip[j]) { if (job_angle[j] == 90) ++n90; else ++nother; }
+    bool base90 = false;                // d_out already holds the overlay of the 90-degree jobs
+    std::vector<int> skip_rest(job_skip, job_skip + njobs);
+    if (n90 > 0 && njobs <= 32) {
+        std::vector<int> skip90(njobs);
+        for (int j = 0; j < njobs; ++j) skip90[j] = job_skip[j] || job_angle[j] != 90;
+        const int rc = pb3d_try_part_carve90(ctx, d_colored, W, H, D, d_mask_sub, d_mask_carve, job_angle, skip90.data(), njobs, d_out);
+        if (rc != PB3D_EUNSUPPORTED) {
+            if (rc != PB3D_OK || nother == 0) return rc;
+            base90 = true;
+            for (int j = 0; j < njobs; ++j) skip_rest[j] = job_skip[j] || job_angle[j] == 90;
+        }
     }
+    job_skip = skip_rest.data();
     void *occ, *carved, *tmp, *keep;
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &occ));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));
@@ -542,7 +586,16 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         any = true;
     }
     if (!any) {
-        PB3D_HIP(hipMemsetAsync(d_out, 0, (size_t)nvox * 3, ctx->stream));
+        if (!base90) PB3D_HIP(hipMemsetAsync(d_out, 0, (size_t)nvox * 3, ctx->stream));
+        return PB3D_OK;
+    }
+    if (base90) {
+        if (wide)
+            hipLaunchKernelGGL(k_part_merge16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, (const u32x4*)keep, (u32x4*)d_out,
+                               ngroups);
+        else
+            hipLaunchKernelGGL(k_part_merge, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox);
+        PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }
     if (wide)
