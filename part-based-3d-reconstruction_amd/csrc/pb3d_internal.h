@@ -92,7 +92,8 @@ static inline unsigned pb3d_stream_blocks(const pb3d_ctx* ctx, i64 work_items, i
 
 // ---- kernels' host launchers used across translation units ---------------------------------
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
-                               const double off[3], const u8* d_mask_wh, u8* d_out);
+                               const double off[3], const u8* d_mask_wh, u8* d_out, const u8* d_mask_src);
+bool pb3d_generic_step_takes_src_mask(const double M[9], i64 W, i64 H, i64 D);
 bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D);
 bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b);
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],

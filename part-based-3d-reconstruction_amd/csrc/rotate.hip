@@ -53,18 +53,22 @@ __device__ __forceinline__ Cell make_cell(const RotParams& p, i64 x, i64 z, i64 
 
 // value of one output voxel from plane y of `in`; taps with an exactly-zero weight add +0.0 and are
 // skipped (this also keeps the index in range: a tap beyond n-1 only ever occurs with weight 0).
-__device__ __forceinline__ u32 sample(const u8* __restrict__ in, const Cell& c, i64 y, i64 H, i64 D) {
+// mask_src (optional): the input is read as carve(in, mask_src) -- a source column (n0, y) with mask_src[n0*H + y] == 0 reads as zeros
+// (the 0-degree carve of process_voxel_grid folded into its first rotation step).
+__device__ __forceinline__ u32 sample(const u8* __restrict__ in, const Cell& c, i64 y, i64 H, i64 D, const u8* __restrict__ mask_src = nullptr) {
     if (c.s0 < 0) return 0;
     const u8* r0 = in + ((i64)c.s0 * H + y) * D + c.s2;
     const u8* r1 = r0 + H * D;
     double acc = 0.0;
     const bool x1 = c.wx1 != 0.0, z1 = c.wz1 != 0.0;
+    const double k0 = (!mask_src || mask_src[(i64)c.s0 * H + y]) ? 1.0 : 0.0;            // v * 1.0 == v, v * 0.0 == +0.0: exact
+    const double k1 = (x1 && (!mask_src || mask_src[((i64)c.s0 + 1) * H + y])) ? 1.0 : 0.0;
     // weights are >= 0; a zero wx0/wz0 (never happens: w0 = 1 - t > 0) needs no special case
-    acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r0[0], c.wx0), c.wz0));
-    if (z1) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r0[1], c.wx0), c.wz1));
+    acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(__dmul_rn((double)r0[0], k0), c.wx0), c.wz0));
+    if (z1) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(__dmul_rn((double)r0[1], k0), c.wx0), c.wz1));
     if (x1) {
-        acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r1[0], c.wx1), c.wz0));
-        if (z1) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn((double)r1[1], c.wx1), c.wz1));
+        acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(__dmul_rn((double)r1[0], k1), c.wx1), c.wz0));
+        if (z1) acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(__dmul_rn((double)r1[1], k1), c.wx1), c.wz1));
     }
     if (!(acc > 0.0)) return 0;
     acc = __dadd_rn(acc, 0.5);
@@ -76,7 +80,7 @@ __device__ __forceinline__ u32 sample(const u8* __restrict__ in, const Cell& c, 
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ in, u8* __restrict__ out,
                                                         const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D,
-                                                        int TY, const int* __restrict__ run_if) {
+                                                        int TY, const int* __restrict__ run_if, const u8* __restrict__ mask_src) {
     if (run_if && *run_if == 0) return;   // second pass of a table-driven step: only when a value > 1 was seen
     const int lane = threadIdx.x & 63;
     const i64 x = (i64)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ i
         u32 r[4] = {0, 0, 0, 0};
         if (keep) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = sample(in, c[q], y, H, D);
+            for (int q = 0; q < 4; ++q) r[q] = sample(in, c[q], y, H, D, mask_src);
         }
         u8* o = out + (x * H + y) * D + z0;
         if (PACK) {
@@ -339,6 +343,15 @@ __device__ __forceinline__ void tr4x4(u32 a0, u32 a1, u32 a2, u32 a3, u32 v[4]) 
     v[2] = pperm(h23, h01, 0x05040100u); v[3] = pperm(h23, h01, 0x07060302u);
 }
 
+// bit q = mask_src[base + q] != 0 for q < np (all ones without a source mask): which planes of one source row are kept by the
+// 0-degree carve that process_voxel_grid folds into its first rotation step; masked planes are not even loaded
+__device__ __forceinline__ u32 src_plane_bits(const u8* __restrict__ mask_src, i64 base, int np) {
+    if (!mask_src) return 0xffffffffu;
+    u32 bits = 0;
+    for (int q = 0; q < np; ++q) bits |= (u32)(mask_src[base + q] != 0) << q;
+    return bits;
+}
+
 __device__ __forceinline__ u32 lut_apply32(u32 lut, u32 t00, u32 t01, u32 t10, u32 t11) {
     u32 L[16];
 #pragma unroll
@@ -366,7 +379,7 @@ constexpr int WMAXU = (WROWS * (WPITCH / 16) + WTHREADS - 1) / WTHREADS;
 template <bool RAGGED>      // false: D % 16 == 0, no piece or run straddles a row end (byte-wise paths compiled out)
 __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
                                                               const CellRec* __restrict__ cells, i64 W, i64 H, i64 D, int TY, int ntz,
-                                                              int ntiles, int* __restrict__ big_flag) {
+                                                              int ntiles, int* __restrict__ big_flag, const u8* __restrict__ mask_src) {
     __shared__ __attribute__((aligned(16))) u32 tile[WROWS * WPITCH];
     __shared__ int bb[4];
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -505,6 +518,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
             const int cu = (int)rc0[r] + (i - (int)ustart[r]);
             // per-lane 32-bit offset + wave-uniform plane base (scalar registers): no per-plane vector address arithmetic
             const u32 voff = (u32)(((i64)bx0 + r) * H * D + (i64)bz0 + 16 * cu);
+            const u32 msrc = src_plane_bits(mask_src, ((i64)bx0 + r) * H + yg, np);       // planes of this source row that survive the folded 0-degree carve
             u32x4 wg[4];
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
@@ -516,7 +530,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void k_rotate_bits32(const u8* __restr
                 for (int q = 0; q < 16; ++q) {
                     const u8* pb = in + (yg + 16 * gg + q) * D;      // uniform
                     d[q] = (u32x4)(0u);
-                    if (16 * gg + q < np) {
+                    if (16 * gg + q < np && ((msrc >> (16 * gg + q)) & 1u)) {
                         if (whole) d[q] = *(const u32x4_a1*)(pb + voff);
                         else {
                             u32 t4[4] = {0, 0, 0, 0};
@@ -661,7 +675,8 @@ __global__ __launch_bounds__(XTHREADS) void k_rot_tile_rows(const CellRec* __res
 template <bool RAGGED>
 __global__ __launch_bounds__(XTHREADS, 4) void k_rotate_bits16w(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
                                                                 const CellRec* __restrict__ cells, const TileRows* __restrict__ info, i64 W, i64 H,
-                                                                i64 D, int TY, int ntz, int ntiles, int* __restrict__ big_flag) {
+                                                                i64 D, int TY, int ntz, int ntiles, int* __restrict__ big_flag,
+                                                                const u8* __restrict__ mask_src) {
     extern __shared__ __attribute__((aligned(16))) u8 xlds[];
     unsigned short* tile = (unsigned short*)xlds;                                  // XROWS * XPITCH
     int* rmin = (int*)(xlds + XROWS * XPITCH * 2);                                 // XROWS
@@ -771,6 +786,7 @@ __global__ __launch_bounds__(XTHREADS, 4) void k_rotate_bits16w(const u8* __rest
             const int cu = (int)rc0[r] + (i - (int)ustart[r]);
             const u32 voff = (u32)(((i64)bx0 + r) * H * D + (i64)bz0 + 16 * cu);
             const bool whole = !RAGGED || (i64)bz0 + 16 * cu + 15 < D || (i64)voff + (yg + 15) * D + 16 <= W * H * D;
+            const u32 msrc = src_plane_bits(mask_src, ((i64)bx0 + r) * H + yg, np);
             u32x4 wg[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -779,7 +795,7 @@ __global__ __launch_bounds__(XTHREADS, 4) void k_rotate_bits16w(const u8* __rest
                 for (int q = 0; q < 8; ++q) {
                     const u8* pb = in + (yg + 8 * g + q) * D;        // uniform
                     d[q] = (u32x4)(0u);
-                    if (8 * g + q < np) {
+                    if (8 * g + q < np && ((msrc >> (8 * g + q)) & 1u)) {
                         if (whole) d[q] = *(const u32x4_a1*)(pb + voff);
                         else {
                             u32 t4[4] = {0, 0, 0, 0};
@@ -855,10 +871,13 @@ bool is_zero(double v) { return v == 0.0; }
 // The table-driven (0/1 data) form of a generic-angle step; *flag is raised on the device when the data was not 0/1.
 //   >= 32 planes: cell table once per step, then the 128 x 128 / 16-plane kernel on large grids or the 64 x 64 / 32-plane one;
 //   fewer planes (or a volume of 4 GiB and more): the 8-plane kernel that evaluates its cells itself.
+static bool table_step_takes_src_mask(i64 W, i64 H, i64 D) { return H >= 32 && W * H * D < (1ll << 32) - 64; }
+
 static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const RotParams& p, const u8* d_mask_wh, u8* d_out,
-                             int* flag) {
+                             int* flag, const u8* d_mask_src) {
     const i64 tiles = ((D + LT - 1) / LT) * ((W + LT - 1) / LT);
-    if (!(H >= 32 && W * H * D < (1ll << 32) - 64)) {
+    if (!table_step_takes_src_mask(W, H, D)) {
+        PB3D_REQUIRE(d_mask_src == nullptr, "pb3d_rotate_carve: this step cannot fold a source mask");
         int TYL = 32;
         while (TYL > 1 && tiles * ((H + TYL - 1) / TYL) < (i64)ctx->cus * 8) TYL >>= 1;
         dim3 lgrid((unsigned)((D + LT - 1) / LT), (unsigned)((W + LT - 1) / LT), (unsigned)((H + TYL - 1) / TYL));
@@ -894,7 +913,7 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         PB3D_REQUIRE(nblkx < (1ll << 31), "pb3d_rotate_carve: grid too large");
         auto kern = D % XCELLS == 0 ? k_rotate_bits16w<false> : k_rotate_bits16w<true>;     // a thread's run is XCELLS = 32 voxels
         hipLaunchKernelGGL(kern, dim3((unsigned)nblkx), dim3(XTHREADS), kXLds, ctx->stream, d_in, d_out, d_mask_wh, (const CellRec*)cells,
-                           (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag);
+                           (const TileRows*)trows, W, H, D, TYX, (int)((D + XT - 1) / XT), (int)xtiles, flag, d_mask_src);
     } else {
         int TYW = 64;        // multiples of 32 planes per workgroup (measured at 1024^3: 32/64 planes 0.76 ms, 128: 0.79, 256: 0.88)
         while (TYW > 32 && tiles * ((H + TYW - 1) / TYW) < (i64)ctx->cus * 4) TYW >>= 1;
@@ -902,14 +921,20 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
         auto kern = D % 16 == 0 ? k_rotate_bits32<false> : k_rotate_bits32<true>;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WTHREADS), 0, ctx->stream, d_in, d_out, d_mask_wh, (const CellRec*)cells, W, H, D,
-                           TYW, (int)((D + LT - 1) / LT), (int)tiles, flag);
+                           TYW, (int)((D + LT - 1) / LT), (int)tiles, flag, d_mask_src);
     }
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
 
+bool pb3d_generic_step_takes_src_mask(const double M[9], i64 W, i64 H, i64 D) {
+    const double ext0 = fabs(M[0]) + fabs(M[2]), ext2 = fabs(M[6]) + fabs(M[8]);
+    const bool tiled = ext0 <= 1.45 && ext2 <= 1.45 && W < 65536 && D < 65536 && W * H * D >= (1ll << 21);
+    return tiled && table_step_takes_src_mask(W, H, D);
+}
+
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
-                               const double off[3], const u8* d_mask_wh, u8* d_out) {
+                               const double off[3], const u8* d_mask_wh, u8* d_out, const u8* d_mask_src) {
     PB3D_REQUIRE(is_zero(M[3]) && M[4] == 1.0 && is_zero(M[5]) && is_zero(M[1]) && is_zero(M[7]) && is_zero(off[1]),
                  "pb3d_rotate_carve: matrix is not a rotation about Y (row 1 must be [0,1,0], M[0][1]=M[2][1]=0, off[1]=0)");
     PB3D_REQUIRE(W < (1ll << 30) && D < (1ll << 30), "pb3d_rotate_carve: axis too long");
@@ -927,7 +952,7 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
         PB3D_TRY(pb3d_scratch(ctx, 15, 64, &f));
         flag = (int*)f;
         PB3D_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
-        PB3D_TRY(launch_table_step(ctx, d_in, W, H, D, p, d_mask_wh, d_out, flag));
+        PB3D_TRY(launch_table_step(ctx, d_in, W, H, D, p, d_mask_wh, d_out, flag, d_mask_src));
     }
     int TY = tiled ? 64 : 16;      // after a table-driven step the grid only reads the flag: keep that launch small
     // keep at least ~8 blocks per CU in flight for small grids
@@ -937,9 +962,9 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     PB3D_REQUIRE(grid.y <= 65535u * 1024u && grid.z <= 65535u, "pb3d_rotate_carve: grid too large");
     const bool pack = (D % 4 == 0) && (((uintptr_t)d_out & 3u) == 0);
     if (pack)
-        hipLaunchKernelGGL(k_rotate_generic<true>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag);
+        hipLaunchKernelGGL(k_rotate_generic<true>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src);
     else
-        hipLaunchKernelGGL(k_rotate_generic<false>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag);
+        hipLaunchKernelGGL(k_rotate_generic<false>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
@@ -955,7 +980,7 @@ int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     const bool row1 = M[3] == 0.0 && M[4] == 1.0 && M[5] == 0.0 && M[1] == 0.0 && M[7] == 0.0 && off[1] == 0.0;
     if (row1 && pb3d_perm_step_ok(M, off, W, D, d_occ, d_out))
         return pb3d_launch_rotate_perm(ctx, d_occ, W, H, D, M, off, nullptr, d_mask_wh, d_out);
-    return pb3d_launch_rotate_generic(ctx, d_occ, W, H, D, M, off, d_mask_wh, d_out);
+    return pb3d_launch_rotate_generic(ctx, d_occ, W, H, D, M, off, d_mask_wh, d_out, nullptr);
 }
 
 int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
@@ -981,8 +1006,10 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     double M1[9], off1[3];
     PB3D_TRY(pb3d_rotinv(angle_interval, M1));
     PB3D_TRY(pb3d_offset(M1, shape, off1));
-    // A permutation-like second step (90 degrees, W + D even) takes the 0-degree carve as its source mask.
-    const bool fuse_first = pb3d_perm_step_ok(M1, off1, W, D, d_occ, d_out) && pb3d_perm_step_ok(M1, off1, W, D, d_occ, d_tmp);
+    // The second step takes the 0-degree carve as its SOURCE mask (one pass over the volume less): a permutation-like step
+    // (90 degrees, W + D even) always, a generic-angle step when it runs through the cell-table kernels.
+    const bool perm1 = pb3d_perm_step_ok(M1, off1, W, D, d_occ, d_out) && pb3d_perm_step_ok(M1, off1, W, D, d_occ, d_tmp);
+    const bool fuse_first = perm1 || (!pb3d_is_perm_step(M1, off1, W, D) && pb3d_generic_step_takes_src_mask(M1, W, H, D));
     const int nlaunch = fuse_first ? nsteps - 1 : nsteps;
     const u8* src = d_occ;
     int li = 0;
@@ -997,7 +1024,7 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
             if (pb3d_perm_step_ok(M, off, W, D, src, dst))
                 PB3D_TRY(pb3d_launch_rotate_perm(ctx, src, W, H, D, M, off, (fuse_first && s == 1) ? d_mask_wh : nullptr, d_mask_wh, dst));
             else
-                PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst));
+                PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst, (fuse_first && s == 1) ? d_mask_wh : nullptr));
         }
         src = dst;
     }

@@ -74,6 +74,9 @@ def main():
         report("M2", "carve_voxel_grid_with_masks(occ,binary)", timeit(lambda: dev.carve_mask(d_occ, S, S, S, 1, d_mwh, d_o1), 20), 2)
     if "M3" in ops:
         report("M3", "process_voxel_grid(occ,binary,90)", timeit(lambda: dev.process_grid(d_occ, S, S, S, d_mwh, 90, d_o1, d_tmp), a.reps), 2)
+    if "M3" in ops:
+        for ai in (45, 60, 30):     # chained: len(range(0, 91, ai)) steps, the 0-degree carve folded into the first rotation
+            report("M3+", f"process_voxel_grid(occ,binary,{ai}): {90 // ai + 1} steps", timeit(lambda: dev.process_grid(d_occ, S, S, S, d_mwh, ai, d_o1, d_tmp), a.reps), 2 * (90 // ai + 1))
     if "M4" in ops:
         M = np.empty(9); off = np.empty(3)
         for ang in (45, 5):
