@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -733,3 +733,16 @@ def test_large_odd_grid_against_oracle_slabs(pb3d_gpu, oracle):
     pv = pb3d_gpu.process_voxel_grid(occ, binary, 45)
     for y0, y1 in slabs:
         assert np.array_equal(pv[:, y0:y1], oracle.process_voxel_grid(np.ascontiguousarray(occ[:, y0:y1]), binary[y0:y1], 45)), ("process45", y0)
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_of_the_cabi(pb3d_gpu, tmp_path):
+    """examples/cabi_demo.c: a C99 program (no Python, no C++) carves through libpb3d.so and checks the result itself."""
+    import subprocess
+    libdir = os.path.dirname(pb3d_gpu._lib.LIB_PATH)
+    exe = str(tmp_path / "cabi_demo")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "cabi_demo.c"),
+                    "-o", exe, "-L" + libdir, "-lpb3d", "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "0 mismatching bytes" in r.stdout and " 0 outside the mask" in r.stdout
