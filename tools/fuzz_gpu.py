@@ -133,6 +133,27 @@ def main():
             saved = {p_: {"deform": {"scale_xz": float(rng.uniform(0.7, 1.3)), "scale_y": float(rng.uniform(0.7, 1.3)), "shift_xz": float(rng.uniform(-10, 10)),
                                       "shift_y": float(rng.uniform(-10, 10))}} for p_ in list(plabels)[:int(rng.integers(1, 5))]}
             ok("deformed_grid", pb3d.build_deformed_grid(cg, plabels, saved, ishape), oracle.build_deformed_grid(cg, plabels, saved, ishape), info)
+            if n % 6 == 0 and W == D:
+                # the whole notebook-1 pipeline (global_carve output -> part jobs -> component-guided carve -> extrusions -> orientation
+                # -> recolouring of the back minarets) on a random blocky part image; the printed log is part of the result
+                PCN = pb3d.PART_COLORS_NP
+                pnames = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome", "main_door", "windows"]
+                palp = np.array([PCN[q] for q in pnames] + [(0, 0, 0)], np.uint8)
+                semf = palp[rng.integers(0, len(palp), (H // 4 + 1, W // 4 + 1))].repeat(4, 0).repeat(4, 1)[:H, :W]
+                ext = semf.copy(); ext[np.all(ext == PCN["main_door"], axis=-1)] = PCN["full_building"]
+                binm = ext.any(-1).astype(np.uint8)
+                gcar = oracle.global_carve(binm, ext, 90)
+                jobsn = [([pnames[int(rng.integers(0, 6))]], int(rng.choice([90, 90, 45]))) for _ in range(int(rng.integers(1, 5)))]
+                sym = {pnames[int(rng.integers(0, 6))]: int(rng.choice([60, 90])) for _ in range(int(rng.integers(0, 3)))}
+                extr = {pnames[int(rng.integers(6, 8))]: int(rng.integers(1, 4)) for _ in range(int(rng.integers(0, 3)))}
+                b1, b2 = io.StringIO(), io.StringIO()
+                with contextlib.redirect_stdout(b1):
+                    fa = pb3d.partwise_carve(gcar, ext, semf, PCN, jobsn, sym, extr)
+                with contextlib.redirect_stdout(b2):
+                    fb = oracle.partwise_carve(gcar, ext, semf, PCN, jobsn, sym, extr)
+                ok("partwise_carve", fa, fb, info + (jobsn, sym, extr))
+                if b1.getvalue() != b2.getvalue():
+                    print("MISMATCH partwise log", info, flush=True); sys.exit(1)
             for st in (1, 2, 3):
                 gp2, gc2, _ = pb3d.voxel_grid_to_points(cg, stride=st); op2, oc2, _ = oracle.voxel_grid_to_points(cg, stride=st)
                 ok("grid_to_points", gp2, op2, info + (st,)); ok("grid_to_points_cols", gc2, oc2, info + (st,))
