@@ -89,6 +89,9 @@ def main():
         ms = timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col), a.reps)
         if "M5" in ops:
             report("M5", "global_carve(binary,rgb,90)", ms, 3)
+            for ai in (45, 60):
+                report("M5+", f"global_carve(binary,rgb,{ai})", timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, ai, d_col), a.reps), 3)
+            dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col)
     if "M6" in ops:
         # six 90-degree part jobs of notebook 1 on the structured grid (labels 1..9 of the synthetic mask are the part colours)
         import synth_host
