@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _hostmem, _lib
 
 
 class DeviceBuffer:
@@ -33,7 +33,7 @@ class DeviceBuffer:
         return self
 
     def download(self, shape, dtype=np.uint8, byte_offset=0):
-        out = np.empty(shape, dtype)
+        out = _hostmem.empty(shape, dtype)
         if byte_offset + out.nbytes > self.nbytes:
             raise ValueError("download exceeds the buffer")
         _lib.check(_lib.load().pb3d_d2h(_lib.ctx(), out.ctypes.data_as(C.c_void_p), self.at(byte_offset), out.nbytes))

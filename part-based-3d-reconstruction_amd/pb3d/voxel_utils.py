@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _hostmem, _lib
 
 __all__ = ["get_voxel_points_by_parts", "voxel_grid_to_points"]
 
@@ -28,8 +28,8 @@ def _compact(grid, colors, stride):
     lib, ctx = _lib.load(), _lib.ctx()
     n = C.c_int64(0)
     _lib.check(lib.pb3d_points_count(ctx, _lib.p_u8(g), A0, A1, A2, Cc, cptr, nc, int(stride), C.byref(n)))
-    pts = np.empty((n.value, 3), np.float32)
-    pc = np.empty((n.value, Cc), np.uint8)
+    pts = _hostmem.empty((n.value, 3), np.float32)
+    pc = _hostmem.empty((n.value, Cc), np.uint8)
     _lib.check(lib.pb3d_points_fill(ctx, n.value, pts.ctypes.data_as(C.POINTER(C.c_float)), _lib.p_u8(pc)))
     return pts, pc
 

@@ -118,3 +118,35 @@ def test_mask_ingest_n3(golden, tmp_path):
     assert np.array_equal(pb3d.load_mask(root, "Taj", "front", 512), golden("f9_Taj_512_masks")["sem"])
     with pytest.raises(FileNotFoundError):
         pb3d.load_mask(root, "Bibi", "front")
+
+
+def test_result_pool_reuses_only_released_memory():
+    """pb3d._hostmem: the opt-in pool serves a result from the memory of an earlier one only after the caller dropped it and
+    everything derived from it (views keep the backing buffer's reference count up); disabled = plain np.empty."""
+    import gc
+    from pb3d import _hostmem as hm
+    hm.set_result_pool(0)
+    a = hm.empty((4, 1 << 20), np.uint8)
+    assert a.flags.owndata                                         # pool off: ordinary arrays
+    hm.set_result_pool(64)
+    try:
+        a = hm.empty((4, 1 << 20), np.uint8); a[:] = 7
+        assert not a.flags.owndata and a.flags.writeable and a.shape == (4, 1 << 20)
+        addr_a = a.ctypes.data
+        b = hm.empty((4, 1 << 20), np.uint8)                       # a is alive: b must not alias it
+        assert b.ctypes.data != addr_a
+        view = a[1:3, ::2]                                          # a derived view keeps the buffer busy after `a` is gone
+        del a; gc.collect()
+        c = hm.empty((3, 1 << 20), np.uint8)
+        assert c.ctypes.data != addr_a and (view == 7).all()
+        del view; gc.collect()
+        d = hm.empty((4, 1 << 20), np.float32).view(np.uint8)       # too large for the released 4 MiB buffer (> capacity rule) -> new
+        e = hm.empty((1 << 20, 4), np.uint8)                         # fits the released buffer: reused
+        assert e.ctypes.data == addr_a and e.shape == (1 << 20, 4)
+        small = hm.empty((10, 10), np.uint8)
+        assert small.flags.owndata                                   # below 1 MiB: never pooled
+        big = hm.empty((80 << 20,), np.uint8)
+        assert big.flags.owndata                                     # above the pool's capacity: plain allocation
+        del b, c, d, e, small, big
+    finally:
+        hm.set_result_pool(0)

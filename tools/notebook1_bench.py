@@ -24,7 +24,8 @@ stored = np.load(os.path.join(GOLDEN, "stored_Taj_voxel_grid.npz"))["voxel_grid"
 PCN = pb3d.PART_COLORS_NP
 pb3d.global_carve(g["binary"][:64, :64].copy(), g["ext"][:64, :64].copy(), 90)   # context + kernels warm
 res = {}
-for rep in range(2):
+pool_mb = int(os.environ.get("PB3D_RESULT_POOL_MB", "0"))      # opt-in result pool (pb3d/_hostmem.py): steady state from the 3rd run
+for rep in range(4 if pool_mb else 2):
     t0 = time.perf_counter()
     gc = pb3d.global_carve(g["binary"], g["ext"], angle_interval=90)
     t1 = time.perf_counter()
@@ -34,7 +35,7 @@ for rep in range(2):
         full = pb3d.partwise_carve(gc, g["ext"], g["sem"], PCN, group_jobs, part_symmetry, extrusion_depths)
     t3 = time.perf_counter()
     res = {"grid": list(gc.shape), "Mvoxel": round(gc.size / 3 / 1e6, 1), "global_carve_s": round(t1 - t0, 3), "part_carve_s": round(t2 - t1, 3),
-           "partwise_carve_s": round(t3 - t2, 3), "reference_cpu_s": {"global_carve": 23.9, "part_carve": 122.7, "partwise_carve": 149.8}}
+           "partwise_carve_s": round(t3 - t2, 3), "result_pool_mb": pool_mb, "reference_cpu_s": {"global_carve": 23.9, "part_carve": 122.7, "partwise_carve": 149.8}}
 oriented = np.flip(pc.transpose(2, 1, 0, 3), axis=1)
 eq = lambda grid, name: np.all(grid == np.array(pb3d.PART_COLORS[name], np.uint8), axis=-1)
 res["results1_pinned_parts_exact"] = bool(all(np.array_equal(eq(oriented, p), eq(stored, p)) for p in ("plinth", "chhatris")))
