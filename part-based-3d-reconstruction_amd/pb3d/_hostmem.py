@@ -3,10 +3,10 @@
 A download into a FRESH np.empty array is dominated by first-touch page faults, not by PCIe: measured on the MI355X hosts,
 219 MB arrive in 4.1 ms when the destination pages exist and in 18.5 ms when they do not (glibc returns arrays above 32 MiB
 to the OS on free, so every np.empty faults again; parallel pre-touching, MADV_HUGEPAGE and MAP_POPULATE did not help).  The
-opt-in pool below keeps the memory of results the caller has RELEASED and hands it out again for later results.
+pool below keeps the memory of results the caller has RELEASED and hands it out again for later results.
 
-    pb3d.set_result_pool(1024)        # megabytes the pool may hold; 0 (the default) = plain np.empty every time
-    # or: PB3D_RESULT_POOL_MB=1024 in the environment
+    pb3d.set_result_pool(4096)        # megabytes the pool may hold (default 1024); 0 = plain np.empty every time
+    # or: PB3D_RESULT_POOL_MB=... in the environment
 
 A pooled result is an ordinary writable ndarray whose .base is the pool's backing buffer (flags.owndata is False -- the one
 observable difference).  A backing buffer is reused only when nothing else references it: NumPy makes every view (slice,
@@ -74,5 +74,4 @@ def empty_like(a):
     return empty(a.shape, a.dtype)
 
 
-if os.environ.get("PB3D_RESULT_POOL_MB", "").isdigit():
-    set_result_pool(int(os.environ["PB3D_RESULT_POOL_MB"]))
+set_result_pool(int(os.environ["PB3D_RESULT_POOL_MB"]) if os.environ.get("PB3D_RESULT_POOL_MB", "").isdigit() else 1024)

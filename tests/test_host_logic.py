@@ -125,6 +125,7 @@ def test_result_pool_reuses_only_released_memory():
     everything derived from it (views keep the backing buffer's reference count up); disabled = plain np.empty."""
     import gc
     from pb3d import _hostmem as hm
+    before = hm._cap_bytes >> 20
     hm.set_result_pool(0)
     a = hm.empty((4, 1 << 20), np.uint8)
     assert a.flags.owndata                                         # pool off: ordinary arrays
@@ -150,3 +151,4 @@ def test_result_pool_reuses_only_released_memory():
         del b, c, d, e, small, big
     finally:
         hm.set_result_pool(0)
+        hm.set_result_pool(before)

@@ -24,7 +24,7 @@ stored = np.load(os.path.join(GOLDEN, "stored_Taj_voxel_grid.npz"))["voxel_grid"
 PCN = pb3d.PART_COLORS_NP
 pb3d.global_carve(g["binary"][:64, :64].copy(), g["ext"][:64, :64].copy(), 90)   # context + kernels warm
 res = {}
-pool_mb = int(os.environ.get("PB3D_RESULT_POOL_MB", "0"))      # opt-in result pool (pb3d/_hostmem.py): steady state from the 3rd run
+pool_mb = pb3d._hostmem._cap_bytes >> 20      # result pool (pb3d/_hostmem.py; PB3D_RESULT_POOL_MB=0 turns it off): steady state from the 3rd run
 for rep in range(4 if pool_mb else 2):
     t0 = time.perf_counter()
     gc = pb3d.global_carve(g["binary"], g["ext"], angle_interval=90)
