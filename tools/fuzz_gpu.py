@@ -17,13 +17,15 @@ def main():
     oracle.set_threads(min(16, len(os.sched_getaffinity(0))))
     pal = np.array(list(oracle.PART_COLORS.values()), np.uint8)
     names = list(oracle.PART_COLORS)
-    t0 = time.time(); n = 0; counts = {}
+    t0 = time.time(); n = 0; counts = {}; last = t0
     def ok(tag, a, b, info):
         counts[tag] = counts.get(tag, 0) + 1
         if not np.array_equal(a, b):
             print("MISMATCH", tag, info, flush=True); sys.exit(1)
     while time.time() - t0 < budget:
         n += 1
+        if time.time() - last > 60:
+            last = time.time(); print(f"... {n} cases, {int(last - t0)} s", flush=True)
         big = n % 7 == 0 or os.environ.get("FUZZ_BIG") == "1"      # FUZZ_BIG=1: every case large enough for the tiled kernels
         lo = 120 if os.environ.get("FUZZ_BIG") == "1" else 1
         W = int(rng.integers(lo, 300 if big else 100)); H = int(rng.integers(max(1, lo // 3), 70 if big else 40)); D = int(rng.integers(lo, 300 if big else 100))
