@@ -109,7 +109,7 @@ def main():
     if not os.path.exists(pb3d._lib.LIB_PATH):      # fresh checkout: compile the HIP extension in tree first (rank 0 only)
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             import __graft_entry__
-            __graft_entry__.build()
+            __graft_entry__.build(quiet=True)
         else:
             for _ in range(600):
                 if os.path.exists(pb3d._lib.LIB_PATH):
