@@ -54,6 +54,27 @@ class DeviceBuffer:
             pass
 
 
+class DeviceGrid:
+    """A (W,H,D[,3]) uint8 voxel grid that lives in HBM.  global_carve(..., on_device=True) returns one; part_carve and
+    partwise_carve accept one in place of the NumPy grid and then return one too, so the notebook-1 chain runs without a
+    single upload or download of the volume; .numpy() brings the result back, .free() releases the memory."""
+
+    def __init__(self, buf, shape):
+        self.buf = buf
+        self.shape = tuple(int(v) for v in shape)
+        self.dtype = np.dtype(np.uint8)
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def numpy(self):
+        return self.buf.download(self.shape)
+
+    def free(self):
+        self.buf.free()
+
+
 def from_numpy(array):
     a = np.ascontiguousarray(array)
     return DeviceBuffer(a.nbytes).upload(a)

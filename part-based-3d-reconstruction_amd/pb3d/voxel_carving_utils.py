@@ -150,8 +150,10 @@ def _job_masks(semantic_mask, group_jobs, W, H, part_colors):
 def part_carve(colored_grid, semantic_mask, group_jobs, visualize=False):
     """Per part group: select its pixels, carve the group's occupancy with its own symmetry
     angle, overlay the survivors; reference :139-160."""
-    g = _lib.as_u8(colored_grid, "colored_grid")
-    if g.ndim != 4 or g.shape[3] != 3:
+    from . import device as dev
+    resident = isinstance(colored_grid, dev.DeviceGrid)          # device-resident chain: no upload, no download
+    g = colored_grid if resident else _lib.as_u8(colored_grid, "colored_grid")
+    if len(g.shape) != 4 or g.shape[3] != 3:
         raise ValueError("colored_grid must be (W,H,D,3)")
     W, H, D, _ = g.shape
     msub, mcarve, angles, skip = _job_masks(semantic_mask, group_jobs, W, H, PART_COLORS)
@@ -159,14 +161,28 @@ def part_carve(colored_grid, semantic_mask, group_jobs, visualize=False):
         if not skip[j] and angles[j] <= 0:
             raise ValueError("range() arg 3 must not be zero" if angles[j] == 0 else "negative angle steps are not supported")
         angles[j] = min(angles[j], 91) if angles[j] > 0 else angles[j]
+    if resident:
+        d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve)
+        d_out = dev.DeviceBuffer(g.nbytes)
+        try:
+            _lib.check(_lib.load().pb3d_part_carve_dev(_lib.ctx(), C.c_void_p(g.buf.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr),
+                                                       angles, skip, len(group_jobs), C.c_void_p(d_out.ptr)))
+            dev.sync()
+        except Exception:
+            d_out.free()
+            raise
+        finally:
+            d_ms.free(); d_mc.free()
+        return dev.DeviceGrid(d_out, g.shape)
     out = _hostmem.empty_like(g)
     _lib.check(_lib.load().pb3d_part_carve(_lib.ctx(), _lib.p_u8(g), W, H, D, _lib.p_u8(msub), _lib.p_u8(mcarve), angles, skip,
                                            len(group_jobs), _lib.p_u8(out)))
     return out
 
 
-def global_carve(binary_mask, semantic_mask_exterior, angle_interval=90, stride=4, visualize=False):
-    """ones((w,h,w)) -> process_voxel_grid -> colours; reference :269-298.  Returns (w,h,w,3) uint8."""
+def global_carve(binary_mask, semantic_mask_exterior, angle_interval=90, stride=4, visualize=False, on_device=False):
+    """ones((w,h,w)) -> process_voxel_grid -> colours; reference :269-298.  Returns (w,h,w,3) uint8
+    (on_device=True: a pb3d.device.DeviceGrid that part_carve / partwise_carve take as is)."""
     b = np.asarray(binary_mask)
     if b.ndim != 2:
         raise ValueError("not enough values to unpack" if b.ndim < 2 else "too many values to unpack (expected 2)")
@@ -182,6 +198,19 @@ def global_carve(binary_mask, semantic_mask_exterior, angle_interval=90, stride=
         # empty angle loop: the all-ones grid is coloured as is
         return apply_colored_mask_to_voxel_grid(np.ones((w, h, w), np.uint8), rgb)
     bt = _lib.truth_u8(b)
+    if on_device:
+        from . import device as dev
+        d_b = dev.from_numpy(bt); d_rgb = dev.from_numpy(rgb)
+        d_out = dev.DeviceBuffer(w * h * w * 3)
+        try:
+            dev.global_carve(d_b, d_rgb, h, w, int(min(angle_interval, 91)), d_out)
+            dev.sync()
+        except Exception:
+            d_out.free()
+            raise
+        finally:
+            d_b.free(); d_rgb.free()
+        return dev.DeviceGrid(d_out, (w, h, w, 3))
     out = _hostmem.empty((w, h, w, 3), np.uint8)
     _lib.check(_lib.load().pb3d_global_carve(_lib.ctx(), _lib.p_u8(bt), _lib.p_u8(rgb), h, w, int(min(angle_interval, 91)),
                                              _lib.p_u8(out)))
@@ -402,8 +431,9 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
     The grid stays resident in HBM from the first stage to the last (one upload, one download); only with
     visualize=True are intermediate grids brought back for plotting."""
     from . import device as dev
-    g = _lib.as_u8(colored_voxel_grid, "colored_voxel_grid")
-    if g.ndim != 4 or g.shape[3] != 3:
+    resident = isinstance(colored_voxel_grid, dev.DeviceGrid)     # then the result is a DeviceGrid too (the input stays the caller's)
+    g = colored_voxel_grid if resident else _lib.as_u8(colored_voxel_grid, "colored_voxel_grid")
+    if len(g.shape) != 4 or g.shape[3] != 3:
         raise ValueError("colored_voxel_grid must be (W,H,D,3)")
     W, H, D, _ = g.shape
     lib, ctx = _lib.load(), _lib.ctx()
@@ -421,16 +451,17 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
         if not skip[j] and angles[j] <= 0:
             raise ValueError("range() arg 3 must not be zero" if angles[j] == 0 else "negative angle steps are not supported")
         angles[j] = min(angles[j], 91) if angles[j] > 0 else angles[j]
-    d_in = dev.from_numpy(g)
-    d_a = dev.DeviceBuffer(g.size)
+    nb = int(np.prod(g.shape, dtype=np.int64))
+    d_in = dev.DeviceBuffer(nb) if resident else dev.from_numpy(g)       # scratch later on; a resident input is only read
+    d_a = dev.DeviceBuffer(nb)
     live = [d_in, d_a]
     try:
         d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve)
         live += [d_ms, d_mc]
-        _lib.check(lib.pb3d_part_carve_dev(ctx, C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr), angles, skip,
+        _lib.check(lib.pb3d_part_carve_dev(ctx, C.c_void_p(g.buf.ptr if resident else d_in.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr), angles, skip,
                                            len(group_jobs), C.c_void_p(d_a.ptr)))
         dev.sync()
-        show(d_a, g.shape, "After part-wise symmetric carving (global symmetry on each part)")
+        show(d_a, tuple(g.shape), "After part-wise symmetric carving (global symmetry on each part)")
         # 2. component-guided symmetry
         sm_ext = np.asarray(semantic_mask_exterior)
         key_ext = _color_key(sm_ext)
@@ -463,7 +494,13 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
             _lib.check(lib.pb3d_orient_dev(ctx, C.c_void_p(d_a.ptr), W, H, D, C.c_void_p(d_b.ptr)))
             _recolor_dev(d_b, (D, H, W), part_colors_np["front_minarets"], part_colors_np["back_minarets"], 2, 0)
             show(d_b, (D, H, W, 3), "After back-minaret recoloring")
+            if resident:
+                live.remove(d_b)
+                return dev.DeviceGrid(d_b, (D, H, W, 3))
             return d_b.download((D, H, W, 3))
+        if resident:
+            live.remove(d_a)
+            return dev.DeviceGrid(d_a, tuple(g.shape))
         return d_a.download(g.shape)
     finally:
         for b in live:

@@ -746,3 +746,31 @@ def test_plain_c_caller_of_the_cabi(pb3d_gpu, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "0 mismatching bytes" in r.stdout and " 0 outside the mask" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Taj_96", "Akbar_64"])
+def test_device_resident_chain(pb3d_gpu, golden, name):
+    """global_carve(on_device=True) -> part_carve -> partwise_carve on DeviceGrid handles (no upload or download of the
+    volume in between) gives the same bytes as the NumPy-in / NumPy-out chain and as the reference's stage outputs."""
+    import contextlib
+    import io
+    from pb3d.device import DeviceGrid
+    g = golden(f"f5_{name}")
+    meta = json.load(open(os.path.join(GOLDEN, "f5_meta.json")))[name]
+    PCN = pb3d_gpu.PART_COLORS_NP
+    d_gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90, on_device=True)
+    assert isinstance(d_gc, DeviceGrid)
+    host_gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90)
+    assert np.array_equal(d_gc.numpy(), host_gc)
+    d_pc = pb3d_gpu.part_carve(d_gc, g["ext"], JOBS_NB1)
+    assert isinstance(d_pc, DeviceGrid) and np.array_equal(d_pc.numpy(), pb3d_gpu.part_carve(host_gc, g["ext"], JOBS_NB1))
+    with contextlib.redirect_stdout(io.StringIO()):
+        d_full = pb3d_gpu.partwise_carve(d_gc, g["ext"], g["sem"], PCN, JOBS_NB1, PART_SYMMETRY, EXTRUSION)
+        d_plain = pb3d_gpu.partwise_carve(d_gc, g["ext"], g["sem"], PCN, JOBS_NB1, PART_SYMMETRY, EXTRUSION, recolor_back_minarets=False)
+    full = d_full.numpy()
+    assert sha(full) == meta["partwise_sha256"] and list(full.shape) == meta["partwise_shape"]
+    assert d_plain.shape == d_gc.shape
+    assert np.array_equal(d_gc.numpy(), host_gc)                       # the resident input is only read
+    for d in (d_gc, d_pc, d_full, d_plain):
+        d.free()

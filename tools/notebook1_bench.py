@@ -36,6 +36,20 @@ for rep in range(4 if pool_mb else 2):
     t3 = time.perf_counter()
     res = {"grid": list(gc.shape), "Mvoxel": round(gc.size / 3 / 1e6, 1), "global_carve_s": round(t1 - t0, 3), "part_carve_s": round(t2 - t1, 3),
            "partwise_carve_s": round(t3 - t2, 3), "result_pool_mb": pool_mb, "reference_cpu_s": {"global_carve": 23.9, "part_carve": 122.7, "partwise_carve": 149.8}}
+# the same chain on device-resident handles: no upload or download of the volume between the stages, one download at the end
+for rep in range(3):
+    t0 = time.perf_counter()
+    d_gc = pb3d.global_carve(g["binary"], g["ext"], angle_interval=90, on_device=True)
+    d_pc = pb3d.part_carve(d_gc, g["ext"], group_jobs)
+    with contextlib.redirect_stdout(io.StringIO()):
+        d_full = pb3d.partwise_carve(d_gc, g["ext"], g["sem"], PCN, group_jobs, part_symmetry, extrusion_depths)
+    t1 = time.perf_counter()
+    full_r = d_full.numpy()
+    t2 = time.perf_counter()
+    same = bool(np.array_equal(full_r, full))
+    for d in (d_gc, d_pc, d_full):
+        d.free()
+res["resident_chain"] = {"global+part+partwise_s": round(t1 - t0, 4), "final_download_s": round(t2 - t1, 4), "equals_host_chain": same}
 oriented = np.flip(pc.transpose(2, 1, 0, 3), axis=1)
 eq = lambda grid, name: np.all(grid == np.array(pb3d.PART_COLORS[name], np.uint8), axis=-1)
 res["results1_pinned_parts_exact"] = bool(all(np.array_equal(eq(oriented, p), eq(stored, p)) for p in ("plinth", "chhatris")))
