@@ -19,7 +19,7 @@ group_jobs = [(["full_building"], 90), (["chhatris"], 90), (["plinth"], 90), (["
 part_symmetry = {"dome": 5, "chhatris": 45, "front_minarets": 5, "small_minarets": 5}
 extrusion_depths = {"main_door": 20, "windows": 10}
 
-g = np.load(os.path.join(GOLDEN, "f9_Taj_512_masks.npz"))
+g = {k: v for k, v in np.load(os.path.join(GOLDEN, "f9_Taj_512_masks.npz")).items()}     # materialised once (NpzFile re-reads per access)
 stored = np.load(os.path.join(GOLDEN, "stored_Taj_voxel_grid.npz"))["voxel_grid"]
 PCN = pb3d.PART_COLORS_NP
 pb3d.global_carve(g["binary"][:64, :64].copy(), g["ext"][:64, :64].copy(), 90)   # context + kernels warm
