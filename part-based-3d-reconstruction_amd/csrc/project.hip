@@ -209,14 +209,20 @@ __device__ __forceinline__ void sweep_f32(const float* __restrict__ pts, i64 n, 
         group_f32<MODE>(P, q, (int)(n & 3), 4 * nfull, sink);
     }
     if (vec) {
-        for (i64 t = gtid; t < nfull; t += gsz) {
+        // the next group's three vectors are requested before this group is projected (software prefetch)
+        f32x4 nx[3];
+        auto fetch = [&](i64 t) {
             const i64 c = REVERSE ? nfull - 1 - t : t;
             const f32x4* g = (const f32x4*)(pts + 12 * c);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const f32x4 v = g[k];     // plain loads: each 128-byte line is shared by three instructions (nontemporal: 1.4x slower)
-                q[4 * k] = v.x; q[4 * k + 1] = v.y; q[4 * k + 2] = v.z; q[4 * k + 3] = v.w;
-            }
+            for (int k = 0; k < 3; ++k) nx[k] = g[k];   // plain loads: each 128-byte line is shared by three instructions (nontemporal: 1.4x slower)
+        };
+        if (gtid < nfull) fetch(gtid);
+        for (i64 t = gtid; t < nfull; t += gsz) {
+            const i64 c = REVERSE ? nfull - 1 - t : t;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { q[4 * k] = nx[k].x; q[4 * k + 1] = nx[k].y; q[4 * k + 2] = nx[k].z; q[4 * k + 3] = nx[k].w; }
+            if (t + gsz < nfull) fetch(t + gsz);
             group_f32<MODE>(P, q, 4, 4 * c, sink);
         }
     } else {
