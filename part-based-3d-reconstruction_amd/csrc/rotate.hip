@@ -616,7 +616,7 @@ constexpr int XMAXU = (XROWS * (XPITCH / 16) + XTHREADS - 1) / XTHREADS;
 // Footprint of every 128 x 128 tile, once per step (it does not depend on the plane): bounding box and, per footprint row,
 // the leftmost / rightmost tap column.  ~64 K LDS atomics per tile -- done here once instead of once per (tile, plane block),
 // by four workgroups per tile (32 x-rows each, rows relative to the quarter's own first row); the tile kernel merges the four.
-struct TileRows { int bb[4]; short rmin[XROWS], rmax[XROWS]; };
+struct TileRows { int bb[4]; int rmin[XROWS], rmax[XROWS]; };
 constexpr int XQ = 4;
 
 __global__ __launch_bounds__(XTHREADS) void k_rot_tile_rows(const CellRec* __restrict__ cells, i64 W, i64 D, int ntz, TileRows* __restrict__ info) {
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(XTHREADS) void k_rot_tile_rows(const CellRec* __res
     __syncthreads();
     TileRows* o = info + (i64)t * XQ + quarter;
     if (tid < 4) o->bb[tid] = fits ? bb[tid] : (tid == 1 && bx1 >= 0 ? 0x7ffffff0 : bb[tid]);   // a quarter that does not fit poisons the tile's box
-    if (tid < XROWS) { o->rmin[tid] = (short)(rmax[tid] >= 0 ? rmin[tid] : 0); o->rmax[tid] = (short)rmax[tid]; }
+    if (tid < XROWS) { o->rmin[tid] = rmax[tid] >= 0 ? rmin[tid] : 0; o->rmax[tid] = rmax[tid]; }
 }
 
 template <bool RAGGED>
