@@ -774,3 +774,31 @@ def test_device_resident_chain(pb3d_gpu, golden, name):
     assert np.array_equal(d_gc.numpy(), host_gc)                       # the resident input is only read
     for d in (d_gc, d_pc, d_full, d_plain):
         d.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mon", ["Akbar", "Bibi", "Charminar", "Itimad", "Taj"])
+def test_five_monuments_deformation_loop_m5(pb3d_gpu, mon):
+    """BASELINE configs[4]: the part-wise deformation re-projection loop on all five monuments (the reference's stored
+    results/1 grids and results/2 final cameras) against digests captured from the reference's notebook-3 closures
+    (tools/gen_golden_m5.py): point extraction, projection, deformed coordinates, per-part IoU, deformed grid."""
+    meta = json.load(open(os.path.join(GOLDEN, "m5_five_monuments_deformation.json")))[mon]
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = pb3d_gpu.PART_COLORS
+    cam = _cams(mon)["front"]
+    names = list(PC.keys())
+    pts, cols = pb3d_gpu.get_voxel_points_by_parts(grid, PC, names)
+    assert len(pts) == meta["n_points"] and sha(pts) == meta["points_sha256"] and sha(cols) == meta["colors_sha256"]
+    H, W = meta["image_shape"]
+    image = pb3d_gpu.project_colored_voxels(pts, cols, cam["cam_pos"], cam["target"], cam["f"], cam["cx"], cam["cy"], H, W)
+    assert sha(image) == meta["image_sha256"]
+    saved = {}
+    for part, c in meta["cases"].items():
+        coords, _ = pb3d_gpu.get_voxel_points_by_parts(grid, PC, [part])
+        cd = pb3d_gpu.deform_coords(coords, meta["image_shape"], meta["grid_shape"][:3], c["deform"])
+        assert len(cd) == c["n_deformed"] and sha(cd) == c["coords_sha256"], part
+        _, iou = pb3d_gpu.evaluate_part_deform(grid, PC, part, c["deform"], image, cam)
+        assert iou == c["iou"], (part, iou, c["iou"])
+        saved[part] = {"deform": c["deform"], "iou": iou}
+    full = pb3d_gpu.build_deformed_grid(grid, PC, saved, meta["image_shape"])
+    assert sha(full) == meta["deformed_grid_sha256"] and int(np.any(full > 0, -1).sum()) == meta["deformed_grid_occupied"]

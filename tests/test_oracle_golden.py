@@ -291,3 +291,31 @@ def test_camera_objective_and_zbuffer_n45(oracle, mon):
         ppts, _ = oracle.get_voxel_points_by_parts(grid, PC, ["front_minarets"])
         vis = oracle.project_part_visible(ppts, cam, zbuf, m["H"], m["W"])
         assert vis.dtype == bool and np.array_equal(vis, g[f"vis_{mon}_{mode}"])
+
+
+@pytest.mark.parametrize("mon", ["Akbar", "Charminar"])
+def test_five_monuments_deformation_loop_m5(oracle, mon):
+    """the oracle on the configs[4] digests captured from the reference's notebook-3 closures (tools/gen_golden_m5.py);
+    the other three monuments (10-15 M points each, ~1 min of CPU apiece; all verified once with this test) are left to
+    the GPU suite to keep the CPU suite short."""
+    meta = json.load(open(os.path.join(GOLDEN, "m5_five_monuments_deformation.json")))[mon]
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = oracle.PART_COLORS
+    cams = json.load(open(os.path.join(GOLDEN, f"stored_{mon}_camera_params_final.json")))
+    cam = {k: (np.array(v, np.float32) if isinstance(v, list) else v) for k, v in cams["front"].items()}
+    names = list(PC.keys())
+    pts, cols = oracle.get_voxel_points_by_parts(grid, PC, names)
+    assert len(pts) == meta["n_points"] and sha(pts) == meta["points_sha256"] and sha(cols) == meta["colors_sha256"]
+    H, W = meta["image_shape"]
+    image = oracle.project_colored_voxels(pts, cols, cam["cam_pos"], cam["target"], cam["f"], cam["cx"], cam["cy"], H, W)
+    assert sha(image) == meta["image_sha256"]
+    saved = {}
+    for part, c in meta["cases"].items():
+        coords, _ = oracle.get_voxel_points_by_parts(grid, PC, [part])
+        cd = oracle.deform_coords(coords, meta["image_shape"], meta["grid_shape"][:3], c["deform"])
+        assert len(cd) == c["n_deformed"] and sha(cd) == c["coords_sha256"], part
+        _, iou = oracle.evaluate_part_deform(grid, PC, part, c["deform"], image, cam)
+        assert iou == c["iou"], (part, iou, c["iou"])
+        saved[part] = {"deform": c["deform"], "iou": iou}
+    full = oracle.build_deformed_grid(grid, PC, saved, meta["image_shape"])
+    assert sha(full) == meta["deformed_grid_sha256"]
