@@ -244,19 +244,32 @@ __global__ __launch_bounds__(256) void k_occupancy_tail(const u8* __restrict__ r
 // Fast path (D % 16 == 0): 16 voxels of one column per thread -> 16 bytes in, 48 bytes out.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void expand16(const u32 keep16, const u32 r, const u32 g, const u32 b, u32 w[12]) {
-    // byte j of the 48 output bytes belongs to voxel j/3 and channel j%3
+    // byte j of the 48 output bytes belongs to voxel j/3 and channel j%3.  The RGB stream repeats every 3 dwords (RGBR GBRG
+    // BRGB); a dword covers parts of two voxels, whose keep masks are joined with a constant byte mask per dword phase.
+    const u32 S[3] = {r | (g << 8) | (b << 16) | (r << 24), g | (b << 8) | (r << 16) | (g << 24), b | (r << 8) | (g << 16) | (b << 24)};
+    u32 m[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) m[v] = (u32)__builtin_amdgcn_sbfe((int)keep16, v, 1);      // 0 or ~0
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        u32 word = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = 4 * k + q;
-            const int vox = j / 3, ch = j % 3;
-            const u32 val = ch == 0 ? r : (ch == 1 ? g : b);
-            word |= (((keep16 >> vox) & 1u) ? val : 0u) << (8 * q);
-        }
-        w[k] = word;
+        const int v0 = (4 * k) / 3, ph = (4 * k) % 3;          // first voxel of the dword and its channel phase
+        // ph 0: bytes v0,v0,v0,v0+1 ; ph 1: v0,v0,v0+1,v0+1 ; ph 2: v0,v0+1,v0+1,v0+1
+        const u32 lo = ph == 0 ? 0x00ffffffu : (ph == 1 ? 0x0000ffffu : 0x000000ffu);
+        w[k] = S[k % 3] & ((m[v0] & lo) | (m[v0 + 1 < 16 ? v0 + 1 : 15] & ~lo));
     }
+}
+
+// bit i = (byte i of the 16 bytes == 1)
+__device__ __forceinline__ u32 ones16(const u32 cw[4]) {
+    u32 bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 t = cw[j] ^ 0x01010101u;                                     // a byte equal to 1 becomes 0
+        const u32 z = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu | t) & 0x80808080u;       // bit 7 of a byte set <=> the byte is non-zero
+        const u32 e = (~z & 0x80808080u) >> 7;                                  // bit 0 of a byte set <=> the byte was 1
+        bits |= ((e * 0x01020408u) >> 24) << (4 * j);                            // gather bits 0, 8, 16, 24 into 4 bits
+    }
+    return bits;
 }
 
 // FLAT = false: D % 16 == 0, a group of 16 voxels lies in one column.  FLAT = true: any D >= 16 -- groups are cut from the
@@ -275,9 +288,7 @@ __global__ __launch_bounds__(256) void k_color_apply16(const u8* __restrict__ ca
             const u8* px = rgb_hw3 + (y * W + x) * 3;
             const u32x4 cv = ld_nt((const u32x4_u*)(carved + 16 * g));
             const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
-            u32 keep16 = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) keep16 |= (byte_of(cw, i) == 1u ? 1u : 0u) << i;
+            const u32 keep16 = ones16(cw);
             u32 w[12];
             const i64 bnd = FLAT ? (xy + 1) * D - 16 * g : 16;     // voxels of the group that belong to column xy
             if (!FLAT || bnd >= 16) expand16(keep16, px[0], px[1], px[2], w);
