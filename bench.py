@@ -50,6 +50,7 @@ def cpu_baseline(S, d_in, m_wh, planes):
     out = None
     for _ in range(5):
         t0 = time.perf_counter()
+        out = None                       # one 3 GB result at a time
         out = orc.carve_voxel_grid_with_masks(sample, mask if planes != S else mask.T)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
@@ -60,23 +61,45 @@ def cpu_baseline(S, d_in, m_wh, planes):
     ref_form = np.where(mask[:, :, None, None].astype(bool), sample, 0)
     t_np = time.perf_counter() - t0
     assert np.array_equal(ref_form, out)
+    del ref_form
     return {"value": round(nvox / best / 1e6, 1), "unit": "Mvoxel/s", "cores": cores, "kind": "port",
-            "sample": f"first {planes} of {S} X-planes of the same synthetic grid ({nvox / 1e6:.0f} Mvoxel, best of <=5 passes)",
+            "sample": (f"the whole {S}^3 synthetic grid" if planes == S else f"first {planes} of {S} X-planes of the same synthetic grid") +
+                      f" ({nvox / 1e6:.0f} Mvoxel, best of <=5 passes; the 1-core np.where form once)",
             "numpy_where_1core_Mvoxel_s": round(nvox / t_np / 1e6, 1)}, out
 
 
-def pmc_traffic(kernel_substr, nvox):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one matches this workload."""
+def source_digest(rel):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(PKG, "csrc", rel), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_traffic(kernel_substr, nvox, source_file):
+    """(HBM bytes per launch, where the figure comes from).  The bytes are PMC counters of a rocprofv3 run of this same
+    command, summarised into profiles/pmc_traffic.json by tools/pmc_summary.py together with a digest of the kernel's source
+    file; a record made from a different version of the kernel is NOT reported (traffic = null) -- counters cannot be read
+    from inside the run, so the only honest alternatives are a fresh profile or no number."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, "no profiles/pmc_traffic.json"
     try:
         for rec in json.load(open(path)):
             if kernel_substr in rec.get("kernel", "") and rec.get("voxels_per_launch") == nvox:
-                return rec.get("hbm_bytes_per_launch")
-    except Exception:
-        return None
-    return None
+                have, want = rec.get("source_sha256"), source_digest(source_file)
+                if have is None or have != want:
+                    return None, (f"stale: profiles/pmc_traffic.json ({rec.get('tag', '')}) was measured on another version of "
+                                  f"csrc/{source_file}; re-run tools/pmc_summary.py")
+                return rec.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {rec.get('tag', '')} (csrc/{source_file} {have})"
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable profiles/pmc_traffic.json: {e}"
+    return None, "no record for this kernel and launch size"
+
+
+def compact_gather_phase(cp, dev, pdist, args, rank, world, S, planes, x0, d_in, d_mwh, d_full, total_vox):
+    """Filled in by the compact (u8 label) reassembly path; see pb3d.dist.carve_gather_labels."""
+    return {"skipped": "compact label gather not built in this revision"}
 
 
 def main():
@@ -87,6 +110,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="grid edge (1024 = the BASELINE metric's config)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-planes", type=int, default=0, help="X-planes of the grid the CPU baseline is timed on (0 = all of them)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank carves its own full S^3 grid (default: the ONE "
                     "S^3 grid of the BASELINE metric is split into X-slabs = strong scaling)")
@@ -163,6 +187,10 @@ def main():
     total_vox = planes * world * S * S
     value = total_vox * args.steps / t / 1e6
     achieved = ALG_BYTES_PER_VOXEL * slab_vox / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_source = pmc_traffic("k_carve_tiles", slab_vox, "carve.hip")
+    # what the kernel must move given the mask: dropped columns are never read (3 B x kept voxels in, 3 B x all voxels out)
+    kept = int(np.count_nonzero(d_mwh.download((S, S))[x0:x1])) * S
+    need = 3 * kept + 3 * slab_vox
     out = {
         "metric": f"Mvoxel/s carved (semantic carve, {S}^3 grid)", "value": round(value, 1), "unit": "Mvoxel/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t / args.steps * 1e3, 4),
@@ -172,26 +200,36 @@ def main():
                                (f"one such grid per GPU, {world} GPU(s)" if args.weak else f"X-slab partition over {world} GPU(s)"),
                    "grid": [S, S, S, 3], "slab_planes_per_gpu": planes, "seed": args.seed, "device": info["name"]},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_carve_tiles", slab_vox),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k_carve_tiles", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
-                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_VOXEL * slab_vox},
+                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_VOXEL * slab_vox,
+                     # `achieved`/`frac` follow SURVEY 8(d): ALGORITHMIC bytes (6 B/voxel) over kernel time.  The bytes that
+                     # actually cross the HBM interface are fewer (masked-out columns are never read): the same time priced
+                     # with those bytes -- the measured PMC traffic when a current profile exists, else the mask's keep count
+                     "hbm_bytes_needed_per_launch": need, "hbm_achieved_GB_s": round((traffic or need) / (kernel_ms * 1e-3) / 1e9, 1),
+                     "hbm_frac": round((traffic or need) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "hbm_bytes_basis": "pmc" if traffic else "3 B x kept voxels + 3 B x all voxels (mask keep count)"},
     }
 
     if world > 1 and not args.no_allgather:
-        # The reassembly all-gather is measured AFTER the headline figure is final.  RCCL start-up is the one step of
-        # this script that depends on the node's fabric state: a watchdog thread makes sure the JSON line is printed
-        # (with the failure recorded) even if it blocks inside the library.
+        # The reassembly all-gather is measured AFTER the headline figure is final.  RCCL start-up is the one step of this
+        # script that depends on the node's fabric state.  If it blocks inside the library, a watchdog thread prints the JSON
+        # line with the failure recorded (rank 0) and ends EVERY rank with exit code 3: a hang is never reported as success,
+        # and nothing tries to go on inside a process whose GPU stream is stuck.  A rank that raises inside the phase tells the
+        # others through the control plane (abort), so they leave together instead of waiting in a collective.
         import threading
+        from pb3d.rendezvous import ControlPlaneAbort, ControlPlaneError
         done = threading.Event()
 
         def watchdog():
             if not done.wait(float(os.environ.get("PB3D_ALLGATHER_TIMEOUT", "150"))):
                 if rank == 0:
-                    out["allgather"] = {"error": "RCCL all-gather phase timed out; carve figures above are unaffected"}
+                    out["allgather"] = {"error": "RCCL all-gather phase timed out (process ended with exit code 3); the carve figures above were final before it started"}
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
+        phase_error = None
         try:
             uid = None
             if rank == 0:
@@ -202,7 +240,13 @@ def main():
             uid = cp.broadcast(uid)
             if not isinstance(uid, bytes):
                 raise RuntimeError(f"rank 0 could not create the RCCL id ({uid})")
+            t_init = time.perf_counter()
             pdist.comm_init(np.frombuffer(uid, np.uint8), rank, world)
+            comm_init_ms = cp.allreduce_max((time.perf_counter() - t_init) * 1e3)
+            seen_rank, seen_n = pdist.comm_info()                 # asked of the communicator, not echoed from our own arguments
+            nranks_seen_min = -cp.allreduce_max(-seen_n)
+            out["rccl"] = {"nranks_seen": seen_n if nranks_seen_min == seen_n else nranks_seen_min, "rank_seen_on_rank0": seen_rank,
+                           "comm_init_ms": round(comm_init_ms, 1)}
             for _ in range(2):
                 pdist.allgather(d_out, d_full, slab_bytes)
             dev.sync(); cp.barrier()
@@ -232,16 +276,27 @@ def main():
             out["allgather"] = {"form": "rgb slabs, in place, one ncclAllGather", "bytes_per_rank": slab_bytes,
                                 "ms": round(ag_ms, 4), "busbw_GB_s": round(slab_bytes * (world - 1) / (ag_ms * 1e-3) / 1e9, 1),
                                 "value_incl_allgather_Mvoxel_s": round(total_vox / t_both / 1e6, 1), "reassembled_volume_verified": ok_all}
+            out["allgather_compact"] = compact_gather_phase(cp, dev, pdist, args, rank, world, S, planes, x0, d_in, d_mwh, d_full, total_vox)
             pdist.comm_destroy()
+        except ControlPlaneAbort as e:
+            phase_error = f"aborted by another rank: {e}"
         except Exception as e:  # noqa: BLE001 - the headline figure must still be reported
-            out["allgather"] = {"error": f"{type(e).__name__}: {e}"}
+            phase_error = f"{type(e).__name__}: {e}"
+            cp.abort(f"rank {rank}: {phase_error}")
+        if phase_error is not None:
+            # the ranks are no longer in step (and RCCL may be half-initialised): report, then end every rank non-zero
+            if rank == 0:
+                out["allgather"] = {"error": phase_error}
+                print(json.dumps(out), flush=True)
+            done.set()
+            os._exit(3)
         try:
             cp.barrier()      # every rank leaves the phase together; still under the watchdog
         finally:
             done.set()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        lab_planes = min(S, 128)
+        lab_planes = min(S, args.cpu_planes) if args.cpu_planes > 0 else S      # default: the WHOLE grid
         m_wh = d_mwh.download((S, S))
         base, cpu_out = cpu_baseline(S, d_in, m_wh, lab_planes)
         gpu_out = d_full.download((lab_planes, S, S, 3))

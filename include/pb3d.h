@@ -234,6 +234,8 @@ int pb3d_synth_palette16(uint8_t palette[48]);
  * d_send into d_recv[rank * bytes_per_rank ...] (d_send may be the rank's own slot: in place). */
 int pb3d_comm_unique_id(uint8_t id[128]);
 int pb3d_comm_init(pb3d_ctx* ctx, const uint8_t id[128], int rank, int nranks);
+/* what the communicator itself reports (ncclCommUserRank / ncclCommCount): lets a launcher confirm RCCL saw every rank */
+int pb3d_comm_info(pb3d_ctx* ctx, int* rank, int* nranks);
 int pb3d_allgather_dev(pb3d_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int pb3d_comm_destroy(pb3d_ctx* ctx);
 /* points partition of the projection (project_colored_voxels, reference utils/projection_utils.py:5-23): a rank projects its

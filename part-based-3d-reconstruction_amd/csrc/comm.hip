@@ -15,6 +15,8 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int*);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*);
     const char* (*GetErrorString)(ncclResult_t);
 };
 
@@ -40,7 +42,9 @@ int load_rccl() {
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.AllReduce || !a.CommDestroy || !a.GetErrorString) {
+    a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))dlsym(lib, "ncclCommUserRank");
+    if (!a.CommCount || !a.CommUserRank || !a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.AllReduce || !a.CommDestroy || !a.GetErrorString) {
         pb3d_set_error("RCCL library lacks a required symbol");
         dlclose(lib);
         return PB3D_ECOMM;
@@ -85,6 +89,15 @@ int pb3d_comm_init(pb3d_ctx* ctx, const uint8_t id[128], int rank, int nranks) {
     ctx->rccl_comm = (void*)comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    return PB3D_OK;
+}
+
+int pb3d_comm_info(pb3d_ctx* ctx, int* rank, int* nranks) {
+    PB3D_REQUIRE(ctx != nullptr && rank && nranks, "pb3d_comm_info: null argument");
+    PB3D_REQUIRE(ctx->rccl_comm != nullptr, "pb3d_comm_info: call pb3d_comm_init first");
+    // asked of RCCL itself, not echoed from pb3d_comm_init's arguments
+    PB3D_NCCL(g_rccl.CommCount((ncclComm_t)ctx->rccl_comm, nranks));
+    PB3D_NCCL(g_rccl.CommUserRank((ncclComm_t)ctx->rccl_comm, rank));
     return PB3D_OK;
 }
 

@@ -5,73 +5,97 @@ A download into a FRESH np.empty array is dominated by first-touch page faults, 
 to the OS on free, so every np.empty faults again; parallel pre-touching, MADV_HUGEPAGE and MAP_POPULATE did not help).  The
 pool below keeps the memory of results the caller has RELEASED and hands it out again for later results.
 
-    pb3d.set_result_pool(4096)        # megabytes the pool may hold (default 1024); 0 = plain np.empty every time
+    pb3d.set_result_pool(4096)        # megabytes the pool may hold; 0 (the default) = plain np.empty every time
     # or: PB3D_RESULT_POOL_MB=... in the environment
 
-A pooled result is an ordinary writable ndarray whose .base is the pool's backing buffer (flags.owndata is False -- the one
-observable difference).  A backing buffer is reused only when nothing else references it: NumPy makes every view (slice,
-reshape, transpose ...) of a result point its .base at the backing buffer, so CPython's reference count of the buffer says
-exactly whether the caller still holds the result or anything derived from it.
+The pool is OPT-IN.  A pooled result is an ordinary writable ndarray whose ultimate .base is a `_Lease` object (flags.owndata
+is False -- the one observable difference).  Ownership does not depend on interpreter internals: every result is created
+through the lease's buffer export, so NumPy itself keeps the lease alive for as long as the result or anything derived from it
+(slice, reshape, transpose, view ...) exists; when the last of them dies the lease is collected and its `weakref.finalize`
+callback puts the backing pages on the free list.  Memory can therefore never be handed out while a live array still maps it.
 """
 import os
-import sys
+import threading
+import weakref
 
 import numpy as np
 
+_lock = threading.Lock()
 _cap_bytes = 0
-_bufs = []          # backing uint8 arrays, most recently used last
+_free = []          # released backing buffers (np.uint8 arrays), most recently released last
+_leased_bytes = 0   # bytes of backing buffers currently lent to live results
+
+
+class _Lease:
+    """Exports one backing buffer; lives exactly as long as the arrays made from it."""
+    __slots__ = ("__array_interface__", "__weakref__")
+
+    def __init__(self, back):
+        self.__array_interface__ = back.__array_interface__
+
+
+def _give_back(back, generation):
+    global _leased_bytes
+    with _lock:
+        _leased_bytes -= back.nbytes
+        if generation == _generation and _cap_bytes and _free_bytes() + back.nbytes <= _cap_bytes:
+            _free.append(back)
+
+
+_generation = 0
 
 
 def set_result_pool(max_megabytes):
     """Let the pool hold up to max_megabytes of released result memory (0 disables it and drops what it holds)."""
-    global _cap_bytes
-    _cap_bytes = max(0, int(max_megabytes)) << 20
-    if _cap_bytes == 0:
-        _bufs.clear()
-    else:
-        _trim(0)
+    global _cap_bytes, _generation
+    with _lock:
+        _cap_bytes = max(0, int(max_megabytes)) << 20
+        _generation += 1                      # buffers lent under the old setting are not taken back
+        _free.clear()
 
 
-def _held():
-    return sum(b.nbytes for b in _bufs)
+def _free_bytes():
+    return sum(b.nbytes for b in _free)
 
 
-def _trim(extra):
-    while _bufs and _held() + extra > _cap_bytes:
-        for i in range(len(_bufs)):
-            if sys.getrefcount(_bufs[i]) == 2:        # the list + getrefcount's argument: nobody else holds it
-                del _bufs[i]
-                break
-        else:
-            return                                      # everything is in use by the caller
+def stats():
+    """(bytes on the free list, bytes lent to live results) -- for tests and diagnostics."""
+    with _lock:
+        return _free_bytes(), _leased_bytes
 
 
 def empty(shape, dtype=np.uint8):
     """np.empty(shape, dtype), served from released result memory when the pool is enabled and has a fitting buffer."""
+    global _leased_bytes
     dtype = np.dtype(dtype)
     shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if _cap_bytes == 0 or nbytes < (1 << 20) or nbytes > _cap_bytes:
         return np.empty(shape, dtype)
-    best = -1
-    for i in range(len(_bufs)):
-        b = _bufs[i]
-        if b.nbytes >= nbytes and b.nbytes <= 2 * nbytes + (1 << 20) and sys.getrefcount(b) == 3 and (best < 0 or b.nbytes < _bufs[best].nbytes):
-            best = i                                    # references: the list, `b`, getrefcount's argument
-        del b
-    if best >= 0:
-        back = _bufs.pop(best)
-    else:
-        _trim(nbytes)
-        if _held() + nbytes > _cap_bytes:
-            return np.empty(shape, dtype)               # the caller holds everything the pool owns: plain allocation
-        back = np.empty(nbytes, np.uint8)
-    _bufs.append(back)
-    return back[:nbytes].view(dtype).reshape(shape)
+    with _lock:
+        best = -1
+        for i, b in enumerate(_free):
+            if nbytes <= b.nbytes <= 2 * nbytes + (1 << 20) and (best < 0 or b.nbytes < _free[best].nbytes):
+                best = i
+        if best >= 0:
+            back = _free.pop(best)
+        else:
+            while _free and _free_bytes() + _leased_bytes + nbytes > _cap_bytes:
+                _free.pop(0)                   # make room: drop the longest-released buffers
+            if _leased_bytes + nbytes > _cap_bytes:
+                return np.empty(shape, dtype)  # the caller holds everything the pool may own: plain allocation
+            back = np.empty(nbytes, np.uint8)
+        _leased_bytes += back.nbytes
+        gen = _generation
+    lease = _Lease(back)
+    weakref.finalize(lease, _give_back, back, gen)       # holds `back` (not the lease) until the lease dies
+    arr = np.asarray(lease)                              # .base is the lease; every view of arr keeps it alive
+    del lease
+    return arr[:nbytes].view(dtype).reshape(shape)
 
 
 def empty_like(a):
     return empty(a.shape, a.dtype)
 
 
-set_result_pool(int(os.environ["PB3D_RESULT_POOL_MB"]) if os.environ.get("PB3D_RESULT_POOL_MB", "").isdigit() else 1024)
+set_result_pool(int(os.environ["PB3D_RESULT_POOL_MB"]) if os.environ.get("PB3D_RESULT_POOL_MB", "").isdigit() else 0)

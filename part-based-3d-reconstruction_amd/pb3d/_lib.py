@@ -84,6 +84,7 @@ _SIGNATURES = {
     "pb3d_synth_palette16": [u8p],
     "pb3d_comm_unique_id": [u8p],
     "pb3d_comm_init": [vp, u8p, C.c_int, C.c_int],
+    "pb3d_comm_info": [vp, intp, intp],
     "pb3d_allgather_dev": [vp, vp, vp, C.c_size_t],
     "pb3d_comm_destroy": [vp],
     "pb3d_project_keys_dev": [vp, vp, C.c_int, vp, i64, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],

@@ -1,11 +1,11 @@
 """Slab sharding of the voxel grid across the GPUs of one node and its reassembly.
 
 The carve path is independent per (x,y) column, so the grid is cut into slabs along its
-slowest axis (axis 0: X in the (W,H,D) working orientation -- the Z axis of the stored
-(D,H,W,3) artefacts).  Slabs are contiguous in memory, every rank runs the same kernels on
+slowest axis (axis 0: X in the (W,H,D) working orientation; in the stored (D,H,W,3)
+artefacts, which are the transposed + flipped grid, working X is stored axis 2).  Slabs are contiguous in memory, every rank runs the same kernels on
 its slab with no communication, and ONE RCCL all-gather reassembles the volume.  One
 process per GPU; the unique id travels over whatever control plane the launcher provides
-(bench.py uses a torch.distributed gloo group only for that and for barriers).
+(bench.py uses pb3d.rendezvous.ControlPlane, a loopback socket star, for that and for barriers).
 """
 import ctypes as C
 
@@ -73,6 +73,13 @@ def new_unique_id():
 def comm_init(unique_id, rank, nranks):
     uid = np.ascontiguousarray(unique_id, np.uint8)
     _lib.check(_lib.load().pb3d_comm_init(_lib.ctx(), _lib.p_u8(uid), int(rank), int(nranks)))
+
+
+def comm_info():
+    """(rank, nranks) as the RCCL communicator itself reports them."""
+    r, n = C.c_int(-1), C.c_int(-1)
+    _lib.check(_lib.load().pb3d_comm_info(_lib.ctx(), C.byref(r), C.byref(n)))
+    return r.value, n.value
 
 
 def allgather(d_send, d_recv, bytes_per_rank):

@@ -2,6 +2,9 @@
 
 Usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <voxels_per_launch> [tag]
 
+Every record carries `source_sha256`: a digest of the csrc/*.hip file that defines the kernel, as it is in the tree when the
+summary is made (make it right after the profiled run).  bench.py reports the traffic only while that digest still matches.
+
 Per MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in SEPARATE --pmc passes
 (TCC slots), both are reported in KiB, WRITE_SIZE is exact for 16-byte-per-lane streaming stores and on
 gfx950 FETCH_SIZE reads exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled.
@@ -26,6 +29,17 @@ def per_kernel(path, counter):
     return {k: statistics.median(v) for k, v in out.items()}
 
 
+def kernel_source_digest(kernel):
+    import glob
+    import hashlib
+    for f in sorted(glob.glob(os.path.join(ROOT, "part-based-3d-reconstruction_amd", "csrc", "*.hip"))):
+        src = open(f, "rb").read()
+        if re.search(rb"\b" + kernel.encode() + rb"\s*\(", src) and b"__global__" in src:
+            for m in re.finditer(rb"__global__[^;{]*?\b" + kernel.encode() + rb"\s*\(", src, re.S):
+                return hashlib.sha256(src).hexdigest()[:16], os.path.basename(f)
+    return None, None
+
+
 def main():
     fetch_csv, write_csv, nvox = sys.argv[1], sys.argv[2], int(sys.argv[3])
     tag = sys.argv[4] if len(sys.argv) > 4 else ""
@@ -40,6 +54,7 @@ def main():
         wr = write[k] * 1024          # KiB -> bytes, exact
         rec = {"kernel": k, "voxels_per_launch": nvox, "fetch_size_kib_raw": fetch[k], "write_size_kib_raw": write[k],
                "read_bytes_corrected": int(rd), "write_bytes": int(wr), "hbm_bytes_per_launch": int(rd + wr), "tag": tag}
+        rec["source_sha256"], rec["source_file"] = kernel_source_digest(k)
         recs = [r for r in recs if not (r["kernel"] == k and r["voxels_per_launch"] == nvox)] + [rec]
         print(rec)
     json.dump(recs, open(path, "w"), indent=1)
