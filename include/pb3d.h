@@ -50,6 +50,11 @@ int pb3d_create(int device, pb3d_ctx** out);
 void pb3d_destroy(pb3d_ctx* ctx);
 int pb3d_device_info(pb3d_ctx* ctx, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes);
 int pb3d_sync(pb3d_ctx* ctx);
+/* Development knobs (results never depend on them; they select between kernels that are all bit-exact).  Initial values come
+ * from the environment, read ONCE in pb3d_create: PB3D_ROTATE_TILE -> "rotate_tile" (0 = choose by size; 64 / 128 / 256 pin the
+ * generic-angle tile kernel -- the parity tests run all of them on the same grids), PB3D_ROT8_TY -> "rot8_ty", PB3D_TUNE0..5 ->
+ * "misc0".."misc5". */
+int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value);
 int pb3d_dev_alloc(pb3d_ctx* ctx, size_t bytes, void** dptr);
 int pb3d_dev_free(pb3d_ctx* ctx, void* dptr);
 int pb3d_dev_memset(pb3d_ctx* ctx, void* dptr, int value, size_t bytes);
@@ -173,6 +178,34 @@ int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b,
 int pb3d_partwise_iou(pb3d_ctx* ctx, const uint8_t* a, const uint8_t* b, int64_t npix,
                       const uint8_t* colors, int ncolors, int64_t* inter, int64_t* uni);
 
+/* ---- K cameras per launch (row N4): the objective of the camera aligner, reference utils/camera_estimation.py:597-603
+ * (`evaluate` = project_colored_voxels + compute_partwise_iou), as the random / coordinate / Powell loops (:606-725) call it
+ * hundreds of times on the same points.  For every camera k: inter[k*ncolors + c], uni[k*ncolors + c] are the counts
+ * pb3d_partwise_iou would return for pb3d_project's image of camera k against the (Himg,Wimg,3) part image d_seg.  The K
+ * images are never materialised; one counter download per call.  pb3d_look_at_batch is the host half: K look-at rotations
+ * (reference utils/camera_geometry.py:3-14) in the caller's float width; dot_mode says how this host's NumPy rounds the
+ * 3-element dot product inside numpy.linalg.norm (0: separate multiplies and adds, 1: one FMA chain from the first product,
+ * 2: exact products accumulated in double then rounded -- float32 only, 3: the FMA chain from the last product, 4: float32 products
+ * accumulated in double -- float32 only, OpenBLAS's sdot tail loop); the Python shim calibrates it against NumPy itself. */
+typedef struct pb3d_camera {
+    double R[9], cam[3], f, cx, cy;
+    int prec[4];
+} pb3d_camera;
+int pb3d_project_iou_batch_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_t* d_cols, int64_t n, const pb3d_camera* cams,
+                               int ncams, int Himg, int Wimg, const uint8_t* d_seg, const uint8_t* colors, int ncolors, int64_t* inter,
+                               int64_t* uni);
+int pb3d_look_at_batch(const void* eye, const void* target, int is_f64, int64_t count, int dot_mode, double* R9);
+/* K deform tuples per launch: the part-wise grid search of reference utils/deformation_estimation.py:148-258 (the slider loop
+ * :100-146 / save_params :262-284 automated).  For tuple k = deforms5[5k .. 5k+4] = (scale_xz, scale_y, kx, ky, kz -- the scalars of
+ * pb3d_deform_count): deform_coords of the part's points, the bounds filter against the (A0,A1,A2) grid, the float32 projection
+ * with ONE fixed camera and the IoU of the part's colour against the (Himg,Wimg,3) image d_seg.  inter[k] / uni[k] are the counts
+ * compute_partwise_iou forms; nvalid[k] counts the in-bounds (point, jitter) evaluations before np.unique (0 <=> upstream's
+ * "No deformed voxels within bounds").  Every point of a part carries the part colour, so the projected image is the set of
+ * pixels hit and neither np.unique nor the write order can change the counts. */
+int pb3d_deform_iou_batch_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, const double* deforms5, int ntuples, int64_t A0, int64_t A1,
+                              int64_t A2, const pb3d_camera* cam, int Himg, int Wimg, const uint8_t* d_seg, const uint8_t color[3],
+                              int64_t* inter, int64_t* uni, int64_t* nvalid);
+
 /* ---- part-wise deformation, reference utils/deformation_estimation.py:70-98 (deform_coords) -------
  * Seven jitters (0, +-0.25 per axis) of the part's points (voxel indices as float32), each centred on
  * its own mean, x/z scaled by sxz and pushed by kx/kz * sign, y scaled by sy and shifted by -ky (the
@@ -218,6 +251,22 @@ int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_
  * out (D,H,W,3) = flip(grid.transpose(2,1,0,3), axis=1) of the (W,H,D,3) grid, C-contiguous. */
 int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, uint8_t* d_out);
 
+/* ---- the 1-byte LABEL form of a semantic grid (row N3: what sits either side of the path) -------------------------------------
+ * A semantic grid / mask only holds (0,0,0) and the colours of a small palette (reference utils/config.py:29-43, masks from
+ * reference utils/mask_utils.py:14-87), so a voxel or pixel is one byte: label 0 <-> (0,0,0), label k <-> palette[k-1]
+ * (npal <= 254 distinct non-black colours).  rgb_to_label fails with PB3D_EINVAL on a colour outside palette + black;
+ * label_to_rgb on a label above npal.  The carve ops take label volumes as they are:
+ *   carve_voxel_grid_with_masks  = pb3d_carve_mask_dev with C = 1 (reference utils/voxel_carving_utils.py:76-87);
+ *   global_carve                 = pb3d_global_carve_label_dev: (w,h,w) labels = label_hw[y,x] where the carve keeps (:269-298);
+ *   part_carve                   = pb3d_part_carve_label_dev, same job description as pb3d_part_carve_dev (:139-160).
+ * Expanding any of their results with pb3d_label_to_rgb_dev gives the bytes of the RGB entry points. */
+int pb3d_rgb_to_label_dev(pb3d_ctx* ctx, const uint8_t* d_rgb, int64_t nvox, const uint8_t* palette, int npal, uint8_t* d_label);
+int pb3d_label_to_rgb_dev(pb3d_ctx* ctx, const uint8_t* d_label, int64_t nvox, const uint8_t* palette, int npal, uint8_t* d_rgb);
+int pb3d_global_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t* d_label_hw, int64_t h, int64_t w, int angle_interval,
+                                uint8_t* d_out);
+int pb3d_part_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_label, int64_t W, int64_t H, int64_t D, const uint8_t* d_mask_sub,
+                              const uint8_t* d_mask_carve, const int* job_angle, const int* job_skip, int njobs, uint8_t* d_out);
+
 /* ---- seeded synthetic inputs generated on the device ---------------------
  * mask16: labels (S,S) uint8 in 0..15 by the closed formula scaled from S=1024; binary and
  * rgb derive from it.  Any output pointer may be NULL.  sem grid: palette[label16 of a
@@ -238,6 +287,17 @@ int pb3d_comm_init(pb3d_ctx* ctx, const uint8_t id[128], int rank, int nranks);
 int pb3d_comm_info(pb3d_ctx* ctx, int* rank, int* nranks);
 int pb3d_allgather_dev(pb3d_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int pb3d_comm_destroy(pb3d_ctx* ctx);
+/* Sharded forms of the carve: one process per GPU, communicator from pb3d_comm_init.  Rank r of n owns the X-planes
+ * [r W/n, (r+1) W/n) (W % n == 0): it carves ITS slab (d_grid_slab: planes x H x D x C bytes; d_mask_wh: the full (W,H) mask) into its
+ * slot of d_out_full and ONE in-place ncclAllGather leaves the whole carved volume on every rank.  Asynchronous like every *_dev
+ * entry.  carve_labels: the same on a label slab (1 B/voxel over xGMI instead of 3), then -- if d_rgb_full is not NULL -- the
+ * local expansion of the reassembled label volume to RGB (labels above npal expand to black; no read-back). */
+int pb3d_carve_mask_sharded_dev(pb3d_ctx* ctx, const uint8_t* d_grid_slab, int64_t W, int64_t H, int64_t D, int C, const uint8_t* d_mask_wh,
+                                uint8_t* d_out_full);
+int pb3d_global_carve_sharded_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t* d_rgb_hw3, int64_t h, int64_t w, int angle_interval,
+                                  uint8_t* d_out_full);
+int pb3d_carve_labels_sharded_dev(pb3d_ctx* ctx, const uint8_t* d_label_slab, int64_t W, int64_t H, int64_t D, const uint8_t* d_mask_wh,
+                                  uint8_t* d_label_full, const uint8_t* palette, int npal, uint8_t* d_rgb_full);
 /* points partition of the projection (project_colored_voxels, reference utils/projection_utils.py:5-23): a rank projects its
  * contiguous range [index_base, index_base + n) of the point list into 64-bit keys (global index + 1) << 24 | rgb (zero = no
  * point); pb3d_allreduce_max_u64_dev (in place, ncclMax) merges the ranks' key images; resolve writes the (H,W,3) image. */

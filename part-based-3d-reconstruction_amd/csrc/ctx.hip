@@ -48,6 +48,13 @@ int pb3d_create(int device, pb3d_ctx** out) {
         return PB3D_ENOMEM;
     }
     ctx->device = device;
+    {
+        auto env_int = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; };
+        ctx->tune_rotate_tile = env_int("PB3D_ROTATE_TILE");
+        ctx->tune_rot8_ty = env_int("PB3D_ROT8_TY");
+        const char* names[6] = {"PB3D_TUNE0", "PB3D_TUNE1", "PB3D_TUNE2", "PB3D_TUNE3", "PB3D_TUNE4", "PB3D_TUNE5"};
+        for (int i = 0; i < 6; ++i) ctx->tune_misc[i] = env_int(names[i]);
+    }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
@@ -71,6 +78,23 @@ int pb3d_create(int device, pb3d_ctx** out) {
         return PB3D_ENOMEM;
     }
     *out = ctx;
+    return PB3D_OK;
+}
+
+int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
+    PB3D_REQUIRE(ctx != nullptr && name != nullptr, "pb3d_set_tuning: null argument");
+    if (!strcmp(name, "rotate_tile")) {
+        PB3D_REQUIRE(value == 0 || value == 64 || value == 128 || value == 256, "pb3d_set_tuning: rotate_tile is 0, 64, 128 or 256");
+        ctx->tune_rotate_tile = value;
+    } else if (!strcmp(name, "rot8_ty")) {
+        PB3D_REQUIRE(value >= 0 && value % 8 == 0, "pb3d_set_tuning: rot8_ty is a multiple of 8");
+        ctx->tune_rot8_ty = value;
+    } else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '5' && !name[5]) {
+        ctx->tune_misc[name[4] - '0'] = value;
+    } else {
+        pb3d_set_error("pb3d_set_tuning: unknown knob '%s'", name);
+        return PB3D_EINVAL;
+    }
     return PB3D_OK;
 }
 

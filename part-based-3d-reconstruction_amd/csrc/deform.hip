@@ -9,6 +9,7 @@
 // 0.25 and the float64 mean NumPy computes is exact_sum / n whatever the summation order; the exact
 // sums are taken with integer atomics.  Non-integer inputs are rejected (PB3D_EUNSUPPORTED).
 #include "pb3d_internal.h"
+#include "project_point.h"
 
 namespace {
 
@@ -108,6 +109,57 @@ __global__ __launch_bounds__(256) void k_scatter_colors(const i64* __restrict__ 
         if (x < 0 || x >= A2 || y < 0 || y >= A1 || z < 0 || z >= A0) { atomicOr(oob, 1); continue; }
         u8* o = grid + ((z * A1 + y) * A2 + x) * 3;
         o[0] = cols[3 * i]; o[1] = cols[3 * i + 1]; o[2] = cols[3 * i + 2];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Row N4, deformation side: K deform tuples per launch.  The part-wise grid search of reference
+// utils/deformation_estimation.py:148-258 (and the slider loop :100-146 it automates) evaluates, for ONE part and a FIXED
+// camera, deform_coords -> bounds filter -> project_colored_voxels -> compute_partwise_iou for hundreds of tuples.  All points
+// of a part carry the part colour, so the projected image is the SET of pixels hit: neither np.unique nor the
+// last-writer-wins order can change it.  One launch evaluates every (tuple, point, jitter), projects the in-bounds integer
+// coordinates (as float32, :128) and marks the pixel in the tuple's private byte image; a second launch counts
+// intersection / union against the part's pixels of the image.  The 7 jitter centres do not depend on the tuple.
+// ------------------------------------------------------------------------------------------------
+struct DeformTuple { double sxz, sy, kx, ky, kz; };
+
+__global__ __launch_bounds__(256) void k_deform_project_batch(const float* __restrict__ pts, i64 n, const DeformTuple* __restrict__ tuples,
+                                                              DeformParams C, pb3d_proj::ProjParams P, i64 A0, i64 A1, i64 A2, i64 npix,
+                                                              u8* __restrict__ marks, unsigned long long* __restrict__ nvalid) {
+    DeformParams D = C;
+    const DeformTuple t = tuples[blockIdx.y];
+    D.sxz = t.sxz; D.sy = t.sy; D.kx = t.kx; D.ky = t.ky; D.kz = t.kz;
+    u8* mark = marks + (i64)blockIdx.y * npix;
+    unsigned long long mine = 0;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < 7 * n; e += (i64)gridDim.x * blockDim.x) {
+        const i64 i = e / 7; const int j = (int)(e - 7 * i);
+        i64 r[3];
+        deform_eval(D, pts + 3 * i, j, r);
+        if (r[0] < 0 || r[0] >= A2 || r[1] < 0 || r[1] >= A1 || r[2] < 0 || r[2] >= A0) continue;
+        ++mine;
+        const double q[3] = {(double)(float)r[0], (double)(float)r[1], (double)(float)r[2]};   // coords_def.astype(np.float32): exact below 2^24
+        int ui, vi;
+        if (pb3d_proj::project_xyz<0>(P, q, &ui, &vi)) mark[(i64)vi * P.Wimg + ui] = 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&nvalid[blockIdx.y], mine);
+}
+
+__global__ __launch_bounds__(256) void k_deform_iou_batch(const u8* __restrict__ marks, const u8* __restrict__ seg, i64 npix, u8 c0, u8 c1, u8 c2,
+                                                          unsigned long long* __restrict__ counts) {
+    const u8* mark = marks + (i64)blockIdx.y * npix;
+    const bool black = c0 == 0 && c1 == 0 && c2 == 0;                       // an unprojected pixel is (0,0,0): it "matches" a black part
+    unsigned long long ni = 0, nu = 0;
+    for (i64 px = (i64)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (i64)gridDim.x * blockDim.x) {
+        const bool a = mark[px] != 0 || black;
+        const bool b = seg[3 * px] == c0 && seg[3 * px + 1] == c1 && seg[3 * px + 2] == c2;
+        ni += (a && b); nu += (a || b);
+    }
+    for (int o = 32; o > 0; o >>= 1) { ni += __shfl_xor(ni, o); nu += __shfl_xor(nu, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (ni) atomicAdd(&counts[2 * blockIdx.y], ni);
+        if (nu) atomicAdd(&counts[2 * blockIdx.y + 1], nu);
     }
 }
 
@@ -227,6 +279,68 @@ int pb3d_scatter_colors_dev(pb3d_ctx* ctx, const int64_t* d_coords, const uint8_
         return PB3D_EINVAL;
     }
     return PB3D_OK;
+}
+
+int pb3d_deform_iou_batch_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, const double* deforms5, int ntuples, int64_t A0, int64_t A1,
+                              int64_t A2, const pb3d_camera* cam, int Himg, int Wimg, const uint8_t* d_seg, const uint8_t color[3],
+                              int64_t* inter, int64_t* uni, int64_t* nvalid) {
+    PB3D_REQUIRE(ctx && n >= 0 && ntuples >= 0 && A0 >= 0 && A1 >= 0 && A2 >= 0 && Himg >= 0 && Wimg >= 0, "pb3d_deform_iou_batch: bad argument");
+    PB3D_REQUIRE(ntuples == 0 || (deforms5 && cam && color && inter && uni && nvalid), "pb3d_deform_iou_batch: null argument");
+    PB3D_REQUIRE(A0 < (1 << 24) && A1 < (1 << 24) && A2 < (1 << 24), "pb3d_deform_iou_batch: grid axis too long for float32 coordinates");
+    for (int k = 0; k < ntuples; ++k) inter[k] = uni[k] = nvalid[k] = 0;
+    const i64 npix = (i64)Himg * Wimg;
+    if (ntuples == 0 || npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_seg && (n == 0 || d_pts), "pb3d_deform_iou_batch: null buffer");
+    pb3d_proj::ProjParams P;
+    PB3D_TRY(pb3d_proj::fill_proj(&P, 0, cam->R, cam->cam, cam->f, cam->cx, cam->cy, cam->prec, Himg, Wimg));
+    DeformParams C;
+    memset(&C, 0, sizeof(C));
+    if (n > 0) PB3D_TRY(centers(ctx, d_pts, n, 0, 0, 0, 0, 0, &C));
+    i64 kc = (256ll << 20) / npix;
+    kc = kc < 1 ? 1 : (kc > 8192 ? 8192 : kc);
+    if (kc > ntuples) kc = ntuples;
+    void *marks, *dt, *cnt;
+    PB3D_TRY(pb3d_scratch(ctx, 12, (size_t)(kc * npix), &marks));
+    PB3D_TRY(pb3d_scratch(ctx, 20, (size_t)kc * sizeof(DeformTuple), &dt));
+    PB3D_TRY(pb3d_scratch(ctx, 21, (size_t)kc * 3 * sizeof(unsigned long long), &cnt));
+    unsigned long long* hc = (unsigned long long*)malloc((size_t)kc * 3 * sizeof(unsigned long long));
+    if (!hc) { pb3d_set_error("pb3d_deform_iou_batch: out of host memory"); return PB3D_ENOMEM; }
+    int rc = PB3D_OK;
+    auto hipok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == PB3D_OK) { pb3d_set_error("%s failed: %s", what, hipGetErrorString(e)); rc = PB3D_ENODEVICE; }
+    };
+    for (i64 k0 = 0; k0 < ntuples && rc == PB3D_OK; k0 += kc) {
+        const i64 kn = ntuples - k0 < kc ? ntuples - k0 : kc;
+        // the caller's array outlives the synchronisation at the end of this pass (struct DeformTuple = 5 doubles)
+        hipok(hipMemcpyAsync(dt, deforms5 + 5 * k0, (size_t)kn * sizeof(DeformTuple), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+        hipok(hipMemsetAsync(marks, 0, (size_t)(kn * npix), ctx->stream), "hipMemsetAsync");
+        hipok(hipMemsetAsync(cnt, 0, (size_t)kn * 3 * sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+        if (rc != PB3D_OK) break;
+        unsigned long long* d_counts = (unsigned long long*)cnt;
+        unsigned long long* d_nvalid = d_counts + 2 * kn;
+        if (n > 0) {
+            i64 per = (7 * n + 255) / 256;
+            const i64 want = ((i64)ctx->cus * 16 + kn - 1) / kn;
+            if (per > want) per = want;
+            if (per < 1) per = 1;
+            hipLaunchKernelGGL(k_deform_project_batch, dim3((unsigned)per, (unsigned)kn), dim3(256), 0, ctx->stream, d_pts, n, (const DeformTuple*)dt, C,
+                               P, A0, A1, A2, npix, (u8*)marks, d_nvalid);
+            hipok(hipGetLastError(), "k_deform_project_batch");
+        }
+        i64 ib = (npix + 255) / 256;
+        const i64 iwant = ((i64)ctx->cus * 8 + kn - 1) / kn;
+        if (ib > iwant) ib = iwant;
+        if (ib < 1) ib = 1;
+        hipLaunchKernelGGL(k_deform_iou_batch, dim3((unsigned)ib, (unsigned)kn), dim3(256), 0, ctx->stream, (const u8*)marks, d_seg, npix, color[0],
+                           color[1], color[2], d_counts);
+        hipok(hipGetLastError(), "k_deform_iou_batch");
+        hipok(hipMemcpyAsync(hc, cnt, (size_t)kn * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+        hipok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        if (rc != PB3D_OK) break;
+        for (i64 k = 0; k < kn; ++k) { inter[k0 + k] = (int64_t)hc[2 * k]; uni[k0 + k] = (int64_t)hc[2 * k + 1]; nvalid[k0 + k] = (int64_t)hc[2 * kn + k]; }
+    }
+    free(hc);
+    return rc;
 }
 
 // host-pointer flavours

@@ -13,6 +13,13 @@ __global__ __launch_bounds__(256) void k_transpose_mask(const u8* __restrict__ h
 
 }  // namespace
 
+// (h,w) truthiness image -> (w,h) 0/1 image (the carving mask in the grid's own axis order)
+int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh) {
+    hipLaunchKernelGGL(k_transpose_mask, dim3(pb3d_stream_blocks(ctx, w * h, 256, 8)), dim3(256), 0, ctx->stream, d_hw, d_wh, h, w);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
 extern "C" {
 
 int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t* d_rgb_hw3, int64_t h, int64_t w,
@@ -39,9 +46,7 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));
     PB3D_HIP(hipMemsetAsync(ones, 1, (size_t)nvox, ctx->stream));
-    hipLaunchKernelGGL(k_transpose_mask, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_bin_hw,
-                       (u8*)mwh, H, W);
-    PB3D_CHECK_LAUNCH();
+    PB3D_TRY(pb3d_transpose_mask_dev(ctx, d_bin_hw, H, W, (u8*)mwh));
     PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
     // colour apply is column-local: run it on the slab with a shifted rgb origin (rgb[y, x0 + xs])
     // -> implemented by handing the kernel the full-width image and the slab's carved rows.

@@ -14,7 +14,7 @@ typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-#define PB3D_NSCRATCH 20
+#define PB3D_NSCRATCH 24
 
 struct pb3d_event {
     hipEvent_t ev;
@@ -25,6 +25,11 @@ struct pb3d_ctx {
     int cus;
     hipStream_t stream;
     bool wide_lds_set;          // hipFuncSetAttribute(max dynamic LDS) done for the wide rotate kernel on this device
+    bool packed_lds_set;        // ... and for the packed 256-tile one
+    // development knobs, read from the environment ONCE in pb3d_create (never on a launch path)
+    int tune_rotate_tile;       // PB3D_ROTATE_TILE: 0 = choose, 64 / 128 / 256 = pin the generic-angle tile kernel
+    int tune_rot8_ty;           // PB3D_ROT8_TY: planes per workgroup of the packed kernel (0 = default)
+    int tune_misc[6];           // PB3D_TUNE0..5: experiment switches of kernels under development
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).
     void* scratch[PB3D_NSCRATCH];
@@ -100,5 +105,6 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
                             const u8* d_mask_src, const u8* d_mask_dst, u8* d_out);
 int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
                           const int* job_angle, const int* job_skip, int njobs, u8* d_out);
+int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh);
 int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, i64 h, i64 w, const double M[9],
                                const double off[3], i64 x0, i64 x1, u8* d_out_slab);

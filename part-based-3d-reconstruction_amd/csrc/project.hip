@@ -10,61 +10,11 @@
 // prec[1..3].  float32 +,-,*,/ are evaluated in double and rounded once (exact since 53 >= 2*24+2);
 // the float32 FMA chain uses the hardware's single-rounded v_fma_f32.
 #include "pb3d_internal.h"
+#include "project_point.h"
 
 namespace {
 
-struct ProjParams {
-    double R[9], cam[3], f, cx, cy;
-    int t0, tm, tu, tv;
-    int Himg, Wimg, pts_f64;
-};
-
-__device__ __forceinline__ double rnd(double v, int is64) { return is64 ? v : (double)(float)v; }
-
-// mode 0: project_colored_voxels (Z < 1e-8 clamped to 1e-8); mode 1: the z-buffer functions of
-// reference utils/eval_helpers_intra.py:134-190 (points with Z <= 1e-6 are dropped, no clamp)
-template <int MODE>
-__device__ __forceinline__ bool project_point(const ProjParams& P, const void* __restrict__ pts, i64 i, int* ui, int* vi,
-                                              double* zout = nullptr) {
-    double p[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        p[k] = P.pts_f64 ? ((const double*)pts)[3 * i + k] : (double)((const float*)pts)[3 * i + k];
-    double pc[3];
-    if (P.t0) {
-        const double d0 = __dsub_rn(p[0], P.cam[0]), d1 = __dsub_rn(p[1], P.cam[1]), d2 = __dsub_rn(p[2], P.cam[2]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            pc[r] = __fma_rn(d2, P.R[3 * r + 2], __fma_rn(d1, P.R[3 * r + 1], __dmul_rn(d0, P.R[3 * r])));
-    } else {
-        const float d0 = __fsub_rn((float)p[0], (float)P.cam[0]), d1 = __fsub_rn((float)p[1], (float)P.cam[1]),
-                    d2 = __fsub_rn((float)p[2], (float)P.cam[2]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            pc[r] = (double)__fmaf_rn(d2, (float)P.R[3 * r + 2],
-                                      __fmaf_rn(d1, (float)P.R[3 * r + 1], __fmul_rn(d0, (float)P.R[3 * r])));
-    }
-    const double X = pc[0], Y = pc[1];
-    double Z = pc[2];
-    if (MODE == 0) {
-        const double zmin = P.t0 ? 1e-8 : (double)(float)1e-8;
-        if (Z < zmin) Z = zmin;
-    } else {
-        const double zthr = P.t0 ? 1e-6 : (double)(float)1e-6;
-        if (!(Z > zthr)) return false;
-        if (zout) *zout = Z;
-    }
-    const double qx = rnd(__ddiv_rn(X, Z), P.t0);
-    const double qy = -rnd(__ddiv_rn(Y, Z), P.t0);
-    const double fm = P.tm ? P.f : (double)(float)P.f;
-    const double mu = rnd(__dmul_rn(qx, fm), P.tm), mv = rnd(__dmul_rn(qy, fm), P.tm);
-    const double u = rnd(__dadd_rn(mu, P.tu ? P.cx : (double)(float)P.cx), P.tu);
-    const double v = rnd(__dadd_rn(mv, P.tv ? P.cy : (double)(float)P.cy), P.tv);
-    const double ur = rint(u), vr = rint(v);
-    if (!(ur >= 0.0 && ur < (double)P.Wimg && vr >= 0.0 && vr < (double)P.Himg)) return false;  // NaN -> false
-    *ui = (int)ur; *vi = (int)vr;
-    return true;
-}
+using namespace pb3d_proj;
 
 // Points are visited from the LAST index down: the winner of a pixel is its largest point index, so once the
 // high indices have claimed their pixels the remaining points mostly lose on a plain read and skip the atomic.
@@ -342,6 +292,78 @@ __global__ __launch_bounds__(256) void k_partwise_iou(const u8* __restrict__ a, 
     if ((int)threadIdx.x < 2 * P.ncolors && acc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row N4: K cameras per launch.  The camera aligner (reference utils/camera_estimation.py:597-603 `evaluate`, driven by the
+// random / coordinate / Powell loops :606-725) re-projects the SAME resident points for every candidate camera and keeps only
+// the per-part IoU against the part image.  One launch projects all K cameras (blockIdx.y = camera; private winner image per
+// camera), a second one resolves every camera's winners to colours on the fly and counts intersections / unions against the
+// part image -- the K projected images are never written -- and ONE copy brings the K x P counters back.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project_points_batch(const void* __restrict__ pts, i64 n, const ProjParams* __restrict__ cams,
+                                                              i64 npix, u32* __restrict__ winners) {
+    const ProjParams P = cams[blockIdx.y];
+    u32* winner = winners + (i64)blockIdx.y * npix;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i64 i = n - 1 - t;
+        int ui, vi;
+        if (project_point<0>(P, pts, i, &ui, &vi)) {
+            u32* w = &winner[(i64)vi * P.Wimg + ui];
+            const u32 mine = (u32)(i + 1);
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(w, mine);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_project_points_batch_f32(const float* __restrict__ pts, i64 n, const ProjF32* __restrict__ cams, int vec,
+                                                                  i64 npix, u32* __restrict__ winners) {
+    const ProjF32 P = cams[blockIdx.y];
+    u32* winner = winners + (i64)blockIdx.y * npix;
+    sweep_f32<0, true>(pts, n, P, vec != 0, [&](i64 i0, const bool* ok, const u32* px, const float*) {
+        u32 cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = ok[k] ? __hip_atomic_load(&winner[px[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+#pragma unroll
+        for (int k = 3; k >= 0; --k)
+            if (cur[k] < (u32)(i0 + k + 1)) atomicMax(&winner[px[k]], (u32)(i0 + k + 1));
+    });
+}
+
+__global__ __launch_bounds__(256) void k_iou_winners_batch(const u32* __restrict__ winners, const u8* __restrict__ cols, const u8* __restrict__ seg,
+                                                           i64 npix, int ncolors, const u8* __restrict__ colors, unsigned long long* __restrict__ counts) {
+    __shared__ u32 acc[64];
+    __shared__ u8 cl[96];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    if (threadIdx.x < 96) cl[threadIdx.x] = (int)threadIdx.x < 3 * ncolors ? colors[threadIdx.x] : (u8)0;
+    __syncthreads();
+    const u32* winner = winners + (i64)blockIdx.y * npix;
+    const int lane = threadIdx.x & 63;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 nloop = (npix + stride - 1) / stride;  // same trip count for every lane: ballots stay convergent
+    for (i64 it = 0; it < nloop; ++it) {
+        const i64 px = it * stride + (i64)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = px < npix;
+        u8 a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+        if (live) {
+            const u32 w = winner[px];
+            if (w) { const u8* c = cols + (i64)(w - 1) * 3; a0 = c[0]; a1 = c[1]; a2 = c[2]; }
+            b0 = seg[3 * px]; b1 = seg[3 * px + 1]; b2 = seg[3 * px + 2];
+        }
+        for (int k = 0; k < ncolors; ++k) {
+            const u8 c0 = cl[3 * k], c1 = cl[3 * k + 1], c2 = cl[3 * k + 2];
+            const bool ma = live && a0 == c0 && a1 == c1 && a2 == c2;
+            const bool mb = live && b0 == c0 && b1 == c1 && b2 == c2;
+            const u32 ni = (u32)__popcll(__ballot(ma && mb)), nu = (u32)__popcll(__ballot(ma || mb));
+            if (lane == 0) {
+                if (ni) atomicAdd(&acc[2 * k], ni);
+                if (nu) atomicAdd(&acc[2 * k + 1], nu);
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * ncolors && acc[threadIdx.x]) atomicAdd(&counts[(i64)blockIdx.y * 64 + threadIdx.x], (unsigned long long)acc[threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -378,17 +400,6 @@ int pb3d_project_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_
     hipLaunchKernelGGL(k_project_resolve, dim3(pb3d_stream_blocks(ctx, npix, 256, 8)), dim3(256), 0, ctx->stream,
                        (const u32*)winner, d_cols, d_img, npix);
     PB3D_CHECK_LAUNCH();
-    return PB3D_OK;
-}
-
-static int fill_proj(ProjParams* P, int pts_f64, const double R[9], const double cam[3], double f, double cx, double cy, const int prec[4],
-                     int Himg, int Wimg) {
-    for (int k = 0; k < 4; ++k) PB3D_REQUIRE(prec[k] == 0 || prec[k] == 1, "pb3d projection: prec[%d] must be 0 or 1", k);
-    PB3D_REQUIRE(prec[1] >= prec[0] && prec[2] >= prec[1] && prec[3] >= prec[1], "pb3d projection: precision may only widen");
-    memcpy(P->R, R, sizeof(P->R)); memcpy(P->cam, cam, sizeof(P->cam));
-    P->f = f; P->cx = cx; P->cy = cy;
-    P->t0 = prec[0]; P->tm = prec[1]; P->tu = prec[2]; P->tv = prec[3];
-    P->Himg = Himg; P->Wimg = Wimg; P->pts_f64 = pts_f64 ? 1 : 0;
     return PB3D_OK;
 }
 
@@ -493,6 +504,89 @@ int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b,
     const unsigned long long* h = (const unsigned long long*)ctx->pinned;
     for (int k = 0; k < ncolors; ++k) { inter[k] = (int64_t)h[2 * k]; uni[k] = (int64_t)h[2 * k + 1]; }
     return PB3D_OK;
+}
+
+
+int pb3d_project_iou_batch_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, const uint8_t* d_cols, int64_t n, const pb3d_camera* cams, int ncams,
+                               int Himg, int Wimg, const uint8_t* d_seg, const uint8_t* colors, int ncolors, int64_t* inter, int64_t* uni) {
+    PB3D_REQUIRE(ctx && (ncams == 0 || (cams && inter && uni)), "pb3d_project_iou_batch: null argument");
+    PB3D_REQUIRE(ncams >= 0 && n >= 0 && n < 0xffffffffll && Himg >= 0 && Wimg >= 0, "pb3d_project_iou_batch: bad sizes");
+    PB3D_REQUIRE(ncolors >= 0 && ncolors <= 32, "pb3d_project_iou_batch: at most 32 colours");
+    for (i64 k = 0; k < (i64)ncams * ncolors; ++k) inter[k] = uni[k] = 0;
+    const i64 npix = (i64)Himg * Wimg;
+    if (ncams == 0 || ncolors == 0 || npix == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_seg && colors && (n == 0 || (d_pts && d_cols)), "pb3d_project_iou_batch: null buffer");
+    // cameras per pass: winner images of one pass stay below 512 MiB, the grid's y dimension below 65536
+    i64 kc = (512ll << 20) / (npix * (i64)sizeof(u32));
+    kc = kc < 1 ? 1 : (kc > 4096 ? 4096 : kc);
+    if (kc > ncams) kc = ncams;
+    void *winners, *dcams, *counts, *dcolors;
+    PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)(kc * npix) * sizeof(u32), &winners));
+    PB3D_TRY(pb3d_scratch(ctx, 20, (size_t)kc * sizeof(ProjParams), &dcams));
+    PB3D_TRY(pb3d_scratch(ctx, 21, (size_t)kc * 64 * sizeof(unsigned long long), &counts));
+    PB3D_TRY(pb3d_scratch(ctx, 22, 128, &dcolors));
+    PB3D_HIP(hipMemcpyAsync(dcolors, colors, (size_t)3 * ncolors, hipMemcpyHostToDevice, ctx->stream));
+    ProjParams* hp = (ProjParams*)malloc((size_t)kc * sizeof(ProjParams));
+    unsigned long long* hc = (unsigned long long*)malloc((size_t)kc * 64 * sizeof(unsigned long long));
+    if (!hp || !hc) { free(hp); free(hc); pb3d_set_error("pb3d_project_iou_batch: out of host memory"); return PB3D_ENOMEM; }
+    int rc = PB3D_OK;
+    for (i64 k0 = 0; k0 < ncams && rc == PB3D_OK; k0 += kc) {
+        const i64 kn = ncams - k0 < kc ? ncams - k0 : kc;
+        bool all_f32 = true;
+        ProjF32* hf = (ProjF32*)hp;                      // the float32 records are smaller: they share the staging area
+        for (i64 k = 0; k < kn && rc == PB3D_OK; ++k) {
+            const pb3d_camera* c = cams + k0 + k;
+            ProjParams P;
+            rc = fill_proj(&P, pts_f64, c->R, c->cam, c->f, c->cx, c->cy, c->prec, Himg, Wimg);
+            ProjF32 F;
+            if (rc == PB3D_OK && !f32_path(P, &F)) all_f32 = false;
+        }
+        if (rc != PB3D_OK) break;
+        for (i64 k = 0; k < kn; ++k) {
+            const pb3d_camera* c = cams + k0 + k;
+            ProjParams P;
+            fill_proj(&P, pts_f64, c->R, c->cam, c->f, c->cx, c->cy, c->prec, Himg, Wimg);
+            if (all_f32) f32_path(P, &hf[k]); else hp[k] = P;
+        }
+        auto hipok = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && rc == PB3D_OK) { pb3d_set_error("%s failed: %s", what, hipGetErrorString(e)); rc = PB3D_ENODEVICE; }
+        };
+        hipok(hipMemcpyAsync(dcams, hp, (size_t)kn * (all_f32 ? sizeof(ProjF32) : sizeof(ProjParams)), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+        hipok(hipMemsetAsync(winners, 0, (size_t)(kn * npix) * sizeof(u32), ctx->stream), "hipMemsetAsync");
+        hipok(hipMemsetAsync(counts, 0, (size_t)kn * 64 * sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+        if (rc != PB3D_OK) break;
+        if (n > 0) {
+            // enough blocks per camera to fill the chip between them, never more than the points need
+            i64 per_cam = all_f32 ? (n / 4 + 256) / 256 : (n + 255) / 256;
+            const i64 want = ((i64)ctx->cus * 16 + kn - 1) / kn;
+            if (per_cam > want) per_cam = want;
+            if (per_cam < 1) per_cam = 1;
+            if (all_f32)
+                hipLaunchKernelGGL(k_project_points_batch_f32, dim3((unsigned)per_cam, (unsigned)kn), dim3(256), 0, ctx->stream, (const float*)d_pts, n,
+                                   (const ProjF32*)dcams, vec_ok(d_pts), npix, (u32*)winners);
+            else
+                hipLaunchKernelGGL(k_project_points_batch, dim3((unsigned)per_cam, (unsigned)kn), dim3(256), 0, ctx->stream, d_pts, n,
+                                   (const ProjParams*)dcams, npix, (u32*)winners);
+            hipok(hipGetLastError(), "k_project_points_batch");
+        }
+        i64 ib = (npix + 255) / 256;
+        const i64 iwant = ((i64)ctx->cus * 8 + kn - 1) / kn;
+        if (ib > iwant) ib = iwant;
+        if (ib < 1) ib = 1;
+        hipLaunchKernelGGL(k_iou_winners_batch, dim3((unsigned)ib, (unsigned)kn), dim3(256), 0, ctx->stream, (const u32*)winners, d_cols, d_seg, npix,
+                           ncolors, (const u8*)dcolors, (unsigned long long*)counts);
+        hipok(hipGetLastError(), "k_iou_winners_batch");
+        hipok(hipMemcpyAsync(hc, counts, (size_t)kn * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+        hipok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        if (rc != PB3D_OK) break;
+        for (i64 k = 0; k < kn; ++k)
+            for (int c = 0; c < ncolors; ++c) {
+                inter[(k0 + k) * ncolors + c] = (int64_t)hc[k * 64 + 2 * c];
+                uni[(k0 + k) * ncolors + c] = (int64_t)hc[k * 64 + 2 * c + 1];
+            }
+    }
+    free(hp); free(hc);
+    return rc;
 }
 
 }  // extern "C"

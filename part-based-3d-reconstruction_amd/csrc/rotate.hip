@@ -864,6 +864,317 @@ __global__ __launch_bounds__(XTHREADS, 4) void k_rotate_bits16w(const u8* __rest
 }
 constexpr size_t kXLds = (size_t)XROWS * XPITCH * 2 + 2 * XROWS * 4 + (XROWS + 2) * 2 + XROWS + XROWS * (XPITCH / 16) + 8 + 4 + 16;
 
+// ------------------------------------------------------------------------------------------------
+// Packed-footprint form for the largest grids: 256 x 256 (x,z) output tiles, 8 planes per pass (k_rotate_bits8p).
+// The read traffic of a tiled rotation is set at LINE level: a footprint row of a T x T tile is a segment that starts and ends
+// inside 128-byte lines, so a tile touches ~ T^2/128 + T (|sin| + |cos|) lines for T^2/128 lines of data -- 2.4x at T = 128 and
+// 45 degrees (k_rotate_bits16w, measured 1.9x behind the L2), 1.7x at T = 256.  What kept T at 128 was LDS: the bounding box of a
+// rotated 256-tile is 364 x 364 voxels.  Here
+//  * the footprint is stored ROW-PACKED: row r occupies the 16-voxel units [ustart[r], ustart[r+1]) of LDS, first column
+//    start16[r] -- exactly the rotated square (T^2 + slack = ~72 KB at one byte per voxel: bit q = plane yg + q), two
+//    workgroups per CU;
+//  * a cell record is ONE dword (footprint row, column within the row, 14 table bits -- entries 0 and 15 of SciPy's result
+//    table are constants); the LDS offsets of its two tap rows come from a 384-entry row table in LDS (one ds_read_b32);
+//  * everything a tile needs besides the voxels (row table, unit list, cell records) is computed ONCE per step by three small
+//    kernels and read through the L2 by every (tile, plane chunk) workgroup;
+//  * workgroup -> (tile, plane chunk): all tiles of one plane chunk run on ONE XCD (blockIdx % 8), so the lines two neighbouring
+//    footprints share meet in that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int PT = 256, PTHREADS = 512;
+constexpr int PROWS = 384;                          // footprint rows: T (|sin| + |cos|) + 2 <= 365
+constexpr int PLDS_DATA = 76 * 1024;                // packed footprint, one byte per voxel
+constexpr int PMAXUNITS = PLDS_DATA / 16;           // 16-voxel units
+constexpr int PUPT = (PMAXUNITS + PTHREADS - 1) / PTHREADS;   // units per thread (10)
+constexpr int PPARTS = 8;                           // set-up: 32 x-rows of a tile per workgroup
+constexpr size_t kPLds = (size_t)PLDS_DATA + PROWS * 4;
+
+struct PPart { int bb[4]; int rmin[PROWS], rmax[PROWS]; };
+struct PTile {
+    int bx0, nrows, nunits, fits;
+    u32 btab[PROWS];                  // low 16: ustart[r] ; high 16 (signed): unit index such that 16 * it + c addresses (r + 1, s2)
+    int start16[PROWS];               // first staged column of row r (multiple of 16)
+    u32 voff[PMAXUNITS];              // voxel offset of unit i at plane 0: (bx0 + r) * H * D + start16[r] + 16 k
+    unsigned short srow[PMAXUNITS];   // r of unit i
+};
+
+// per (tile, 32 x-rows): bounding rows and per-row tap extents, rows relative to the part's own first row
+__global__ __launch_bounds__(PTHREADS) void k_rot8_parts(const CellRec* __restrict__ cells, i64 W, i64 D, int ntz, PPart* __restrict__ parts) {
+    __shared__ int bb[4];
+    __shared__ int rmin[PROWS], rmax[PROWS];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x / PPARTS, part = blockIdx.x % PPARTS;
+    const i64 x0 = (i64)(t / ntz) * PT, z0 = (i64)(t % ntz) * PT;
+    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+    if (tid < PROWS) { rmin[tid] = 0x7fffffff; rmax[tid] = -1; }
+    __syncthreads();
+    // 512 threads on 32 x-rows x 256 z: 16 threads per row, 16 cells each
+    const int zl = (tid & 15) * 16, xl0 = part * (PT / PPARTS) + (tid >> 4);
+    const i64 x = x0 + xl0;
+    int mn0 = 0x7fffffff, mx0 = -1;
+    u32 src[16], lut[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const i64 z = z0 + zl + c;
+        src[c] = 0xffffffffu; lut[c] = 0;
+        if (x < W && z < D) { const CellRec r = cells[x * D + z]; src[c] = r.src; lut[c] = r.lut; }
+        if (src[c] == 0xffffffffu) continue;
+        const int s0 = (int)(src[c] >> 16), e0 = s0 + (int)((lut[c] >> 16) & 1u);
+        mn0 = s0 < mn0 ? s0 : mn0; mx0 = e0 > mx0 ? e0 : mx0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn0 = min(mn0, __shfl_xor(mn0, o)); mx0 = max(mx0, __shfl_xor(mx0, o)); }
+    if ((tid & 63) == 0 && mx0 >= 0) { atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1];
+    const bool fits = bx1 >= 0 && bx1 - bx0 + 2 <= PROWS;
+    if (fits) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (src[c] == 0xffffffffu) continue;
+            const int rr = (int)(src[c] >> 16) - bx0, s2 = (int)(src[c] & 0xffffu);
+            const int e2 = s2 + (int)((lut[c] >> 17) & 1u);
+            atomicMin(&rmin[rr], s2); atomicMax(&rmax[rr], e2);
+            if ((lut[c] >> 16) & 1u) { atomicMin(&rmin[rr + 1], s2); atomicMax(&rmax[rr + 1], e2); }
+        }
+    }
+    __syncthreads();
+    PPart* o = parts + (i64)t * PPARTS + part;
+    if (tid < 4) o->bb[tid] = fits ? bb[tid] : (tid == 1 && bx1 >= 0 ? 0x7ffffff0 : bb[tid]);   // a part that does not fit poisons the tile
+    if (tid < PROWS) { o->rmin[tid] = rmax[tid] >= 0 ? rmin[tid] : 0; o->rmax[tid] = rmax[tid]; }
+}
+
+// per tile: merge the parts, lay the rows out in LDS, list the staging units
+__global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict__ parts, i64 H, i64 D, PTile* __restrict__ tiles) {
+    __shared__ int sb[2 + PPARTS];
+    __shared__ int lo[PROWS + 1], hi[PROWS + 1], ust[PROWS + 2];
+    __shared__ int wsum[PTHREADS / 64];
+    const int tid = threadIdx.x;
+    const PPart* qi = parts + (i64)blockIdx.x * PPARTS;
+    PTile* ti = tiles + blockIdx.x;
+    if (tid < 64) {                     // wave 0: bounding rows over the parts
+        int b0 = 0x7fffffff, b1 = -1;
+        if (tid < PPARTS && qi[tid].bb[1] >= 0) { b0 = qi[tid].bb[0]; b1 = qi[tid].bb[1]; }
+        if (tid < PPARTS) sb[2 + tid] = b1 >= 0 ? b0 : 0x7fffffff;          // first row of part `tid` (none: huge)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { b0 = min(b0, __shfl_xor(b0, o)); b1 = max(b1, __shfl_xor(b1, o)); }
+        if (tid == 0) { sb[0] = b0; sb[1] = b1; }
+    }
+    __syncthreads();
+    const int bx0 = sb[0], bx1 = sb[1];
+    const int nrows = bx1 >= 0 ? bx1 - bx0 + 1 : 0;
+    const bool rows_fit = nrows + 1 <= PROWS;
+    // row tid of the tile = row tid + bx0 - bb_q[0] of part q; the 16 loads of a row are independent of each other
+    int n_units = 0;
+    if (tid <= PROWS) {
+        int l = 0x7fffffff, h = -1;
+        if (rows_fit && tid < nrows) {
+            int lq[PPARTS], hq[PPARTS];
+#pragma unroll
+            for (int q = 0; q < PPARTS; ++q) {
+                const int rq = sb[2 + q] == 0x7fffffff ? -1 : tid + bx0 - sb[2 + q];
+                const bool ok = rq >= 0 && rq < PROWS;
+                lq[q] = ok ? qi[q].rmin[rq] : 0; hq[q] = ok ? qi[q].rmax[rq] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < PPARTS; ++q)
+                if (hq[q] >= 0) { l = min(l, lq[q]); h = max(h, hq[q]); }
+        }
+        lo[tid] = h >= 0 ? (l & ~15) : 0;
+        hi[tid] = h;
+        n_units = h >= 0 ? ((h - (l & ~15)) >> 4) + 1 : 0;
+    }
+    // exclusive prefix sum of the per-row unit counts (rows 0..PROWS, one per thread)
+    int inc = n_units;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((tid & 63) >= o) inc += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    if (tid <= PROWS) ust[tid] = base + inc - n_units;
+    if (tid == PTHREADS - 1) ust[PROWS + 1] = base + inc;
+    __syncthreads();
+    const int nunits = ust[PROWS + 1];
+    const bool fits = rows_fit && nunits <= PMAXUNITS;
+    if (tid == 0) { ti->bx0 = bx0; ti->nrows = nrows; ti->nunits = fits ? nunits : 0; ti->fits = (fits || nrows == 0) ? 1 : 0; }
+    if (tid < PROWS) {
+        const int r = tid;
+        // row r + 1 through row r's column index: 16 * nxt + (s2 - lo[r]) = 16 * ust[r + 1] + (s2 - lo[r + 1])
+        int nxt = ust[r];
+        if (hi[r] >= 0 && hi[r + 1] >= 0) nxt = ust[r + 1] + ((lo[r] - lo[r + 1]) >> 4);     // both multiples of 16: exact
+        ti->btab[r] = ((u32)ust[r] & 0xffffu) | ((u32)nxt << 16);
+        ti->start16[r] = lo[r];
+    }
+    if (fits) {
+        for (int i = tid; i < nunits; i += PTHREADS) {            // unit i -> its row: the last r with ust[r] <= i
+            int a = 0, b = PROWS;
+            while (a < b) { const int m = (a + b + 1) >> 1; if (ust[m] <= i) a = m; else b = m - 1; }
+            ti->voff[i] = (u32)(((i64)bx0 + a) * H * D + lo[a] + 16 * (i - ust[a]));
+            ti->srow[i] = (unsigned short)a;
+        }
+    }
+}
+
+// one dword per cell: footprint row | column within the row << 9 | table bits 1..14 << 18 ; all ones = outputs 0
+__global__ __launch_bounds__(256) void k_rot8_pack(const CellRec* __restrict__ cells, const PTile* __restrict__ tiles, i64 W, i64 D, int ntz,
+                                                   u32* __restrict__ recs) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * D) return;
+    const i64 x = i / D, z = i - x * D;
+    const PTile* ti = tiles + (x / PT) * ntz + z / PT;
+    const CellRec c = cells[i];
+    u32 rec = 0xffffffffu;
+    if (c.src != 0xffffffffu && ti->fits) {
+        const int r = (int)(c.src >> 16) - ti->bx0;
+        const int col = (int)(c.src & 0xffffu) - ti->start16[r];
+        rec = (u32)r | ((u32)col << 9) | (((c.lut >> 1) & 0x3fffu) << 18);
+    }
+    recs[i] = rec;
+}
+
+__device__ __forceinline__ u32 lut_apply14(u32 lut14, u32 t00, u32 t01, u32 t10, u32 t11) {
+    u32 L[16];
+    L[0] = 0u; L[15] = ~0u;                                   // no tap set -> 0 ; all four set -> the weights sum to 1 -> 1
+#pragma unroll
+    for (int k = 1; k < 15; ++k) L[k] = (u32)__builtin_amdgcn_sbfe((int)lut14, k - 1, 1);
+    u32 g[8], h[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = bsel(t00, L[2 * j + 1], L[2 * j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = bsel(t01, g[2 * j + 1], g[2 * j]);
+    const u32 m0 = bsel(t10, h[1], h[0]), m1 = bsel(t10, h[3], h[2]);
+    return bsel(t11, m1, m0);                                 // bits 0..7: planes ; bits 8.. : garbage (callers pick byte 0)
+}
+
+// bit q of the result: byte q of the 8 mask bytes at p is non-zero (q < np)
+__device__ __forceinline__ u32 mask8(const u8* __restrict__ p, int np) {
+    u32 bits = 0;
+    if ((((uintptr_t)p) & 3u) == 0 && np == 8) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            u32 t4 = *(const u32*)(p + 4 * k);
+            t4 |= t4 >> 4; t4 |= t4 >> 2; t4 |= t4 >> 1; t4 &= 0x01010101u;
+            bits |= ((t4 * 0x01020408u) >> 24) << (4 * k);
+        }
+    } else {
+        for (int q = 0; q < np; ++q) bits |= (u32)(p[q] != 0) << q;
+    }
+    return bits;
+}
+
+template <bool SRCMASK>
+__global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
+                                                               const u32* __restrict__ recs, const PTile* __restrict__ tiles, i64 W, i64 H, i64 D,
+                                                               int TY, int ntz, int ntiles, int nchunks, int* __restrict__ big_flag,
+                                                               const u8* __restrict__ mask_src, int abl) {
+    extern __shared__ __attribute__((aligned(16))) u8 plds[];
+    u32* btab = (u32*)(plds + PLDS_DATA);
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int t = slot % ntiles;
+    const int chunk = (slot / ntiles) * 8 + (int)(blockIdx.x & 7u);
+    if (chunk >= nchunks) return;                      // whole workgroup, before any barrier
+    const PTile* ti = tiles + t;
+    if (!ti->fits) { if (tid == 0) atomicOr(big_flag, 1); return; }
+    const i64 x0 = (i64)(t / ntz) * PT, z0 = (i64)(t % ntz) * PT;
+    const i64 y_beg = (i64)chunk * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    const int nunits = ti->nunits;
+    const i64 bx0 = ti->bx0;
+    for (int i = tid; i < PROWS; i += PTHREADS) btab[i] = ti->btab[i];
+    u32 uvoff[PUPT], umrow[PUPT];
+#pragma unroll
+    for (int j = 0; j < PUPT; ++j) {
+        const int i = tid + PTHREADS * j;
+        uvoff[j] = i < nunits ? ti->voff[i] : 0xffffffffu;
+        umrow[j] = (SRCMASK && i < nunits) ? (u32)((bx0 + ti->srow[i]) * H) : 0u;
+    }
+    __syncthreads();
+    u32 hib = 0;
+    const int zc = 16 * (tid & 15);                    // this thread's 16-cell run inside a tile row
+    for (i64 yg = y_beg; yg < y_end; yg += 8) {
+        const int np = (int)(y_end - yg < 8 ? y_end - yg : 8);
+        // ---- stage the footprint of 8 planes: 16 voxels x 8 planes per unit; the next unit's loads are issued before this one is packed
+        u32x4 d[2][8];
+        auto load_unit = [&](u32x4 (&dd)[8], int j) {
+            const u32 voff = uvoff[j];
+            u32 msrc = 0xffu;
+            if (SRCMASK && voff != 0xffffffffu) msrc = mask8(mask_src + umrow[j] + yg, np);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const u8* pb = in + (yg + q) * D;              // uniform
+                dd[q] = (u32x4)(0u);
+                if (voff != 0xffffffffu && q < np && ((msrc >> q) & 1u)) dd[q] = *(const u32x4*)(pb + voff);
+            }
+        };
+        if (!(abl & 2)) load_unit(d[0], 0);
+#pragma unroll
+        for (int j = 0; j < PUPT; ++j) {
+            if (abl & 2) break;
+            if (j + 1 < PUPT) load_unit(d[(j + 1) & 1], j + 1);
+            if (uvoff[j] != 0xffffffffu) {
+                u32x4 wv = (u32x4)(0u);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const u32x4 dd = d[j & 1][q];
+                    wv.x |= (dd.x & 0x01010101u) << q; wv.y |= (dd.y & 0x01010101u) << q;
+                    wv.z |= (dd.z & 0x01010101u) << q; wv.w |= (dd.w & 0x01010101u) << q;
+                    hib |= dd.x | dd.y | dd.z | dd.w;
+                }
+                *(u32x4*)(plds + 16 * (tid + PTHREADS * j)) = wv;
+            }
+        }
+        __syncthreads();
+        // ---- evaluate: 4 quarter passes of 64 x-rows; a thread owns two 16-cell runs (rows xa and xa + 32) per quarter
+#pragma unroll 1
+        for (int qq = 0; qq < 4; ++qq) {
+            if (abl & 1) break;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const i64 x = x0 + 64 * qq + 32 * h + (tid >> 4);
+                const i64 z = z0 + zc;
+                if (x >= W || z >= D) continue;
+                u32 rec[16];
+                const u32x4* rp = (const u32x4*)(recs + x * D + z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const u32x4 v = rp[k]; rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w; }
+                const u32 mbits = mask_wh ? mask8(mask_wh + x * H + yg, np) : 0xffu;
+                u32 G[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32 R[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32 rc = rec[4 * i + c];
+                        R[c] = 0;
+                        if (rc != 0xffffffffu) {
+                            const u32 tb = btab[rc & 511u], col = (rc >> 9) & 511u;
+                            const u32 o0 = ((tb & 0xffffu) << 4) + col;
+                            const u32 o1 = (u32)(((int)tb >> 16) * 16) + col;
+                            R[c] = lut_apply14(rc >> 18, plds[o0], plds[o0 + 1], plds[o1], plds[o1 + 1]);
+                        }
+                    }
+                    const u32 l01 = pperm(R[1], R[0], 0x0c0c0400u), l23 = pperm(R[3], R[2], 0x0c0c0400u);   // byte 0 of each pair
+                    G[i] = l01 | (l23 << 16);
+                }
+                const u32 ooff = (u32)(x * H * D + z);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q >= np) break;
+                    const u32 keep = ((mbits >> q) & 1u) ? 0x01010101u : 0u;
+                    u32x4 r;
+                    r.x = (G[0] >> q) & keep; r.y = (G[1] >> q) & keep; r.z = (G[2] >> q) & keep; r.w = (G[3] >> q) & keep;
+                    u8* pb = out + (yg + q) * D;                          // uniform
+                    *(u32x4*)(pb + ooff) = r;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
+}
+
 bool is_zero(double v) { return v == 0.0; }
 
 }  // namespace
@@ -894,9 +1205,50 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
     hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells);
     PB3D_CHECK_LAUNCH();
     const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
-    // PB3D_ROTATE_TILE=64 / 128 pins the tile kernel (parity tests run both on the same grids)
-    const char* pin = getenv("PB3D_ROTATE_TILE");
-    const bool wide = pin ? atoi(pin) == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2);
+    // ctx->tune_rotate_tile (PB3D_ROTATE_TILE = 64 / 128 / 256, read once in pb3d_create) pins the tile kernel: the parity tests run
+    // all of them on the same grids
+    const int pin = ctx->tune_rotate_tile;
+    const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
+    const bool packed_ok = D % 16 == 0 && W * H * D < (1ll << 32) - 64 && H >= 8;
+    const bool packed = packed_ok && (pin ? pin == 256 : (W >= 512 && D >= 512 && ptiles * ((H + 15) / 16) >= (i64)ctx->cus * 4));
+    if (packed) {
+        if (!ctx->packed_lds_set) {
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            ctx->packed_lds_set = true;
+            if (ctx->tune_misc[5] == 1) {          // development: how many workgroups of the packed kernel fit a CU
+                for (int lds = 64 * 1024; lds <= (int)kPLds; lds += 2048) {
+                    int nb = -1;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rotate_bits8p<false>, PTHREADS, (size_t)lds);
+                    fprintf(stderr, "[pb3d] k_rotate_bits8p occupancy: %d workgroups/CU at %d B of LDS\n", nb, lds);
+                }
+                int nb = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rotate_bits8p<false>, PTHREADS, kPLds);
+                fprintf(stderr, "[pb3d] k_rotate_bits8p occupancy: %d workgroups/CU at %zu B of LDS (used)\n", nb, kPLds);
+            }
+        }
+        const int ntz = (int)((D + PT - 1) / PT);
+        void *parts, *tinfo, *recs;
+        PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)ptiles * PPARTS * sizeof(PPart), &parts));
+        PB3D_TRY(pb3d_scratch(ctx, 18, (size_t)ptiles * sizeof(PTile), &tinfo));
+        PB3D_TRY(pb3d_scratch(ctx, 19, (size_t)(W * D) * sizeof(u32), &recs));
+        hipLaunchKernelGGL(k_rot8_parts, dim3((unsigned)(ptiles * PPARTS)), dim3(PTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D, ntz, (PPart*)parts);
+        hipLaunchKernelGGL(k_rot8_tiles, dim3((unsigned)ptiles), dim3(PTHREADS), 0, ctx->stream, (const PPart*)parts, H, D, (PTile*)tinfo);
+        hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, (const CellRec*)cells, (const PTile*)tinfo, W, D,
+                           ntz, (u32*)recs);
+        PB3D_CHECK_LAUNCH();
+        int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : 32;              // planes per workgroup (multiple of 8)
+        while (TYP > 8 && ptiles * ((H + TYP - 1) / TYP) < (i64)ctx->cus * 4) TYP >>= 1;
+        const int nchunks = (int)((H + TYP - 1) / TYP);
+        const i64 nblk = 8 * ptiles * ((nchunks + 7) / 8);
+        PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
+        auto kern = d_mask_src ? k_rotate_bits8p<true> : k_rotate_bits8p<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const u32*)recs,
+                           (const PTile*)tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0]);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
+    const bool wide = pin ? pin == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2);
     if (wide) {
         if (!ctx->wide_lds_set) {       // > 64 KiB of LDS per workgroup has to be allowed once per device
             PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));

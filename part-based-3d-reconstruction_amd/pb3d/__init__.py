@@ -11,7 +11,8 @@ from .camera_estimation import CameraObjective, compute_partwise_iou, projection
 from .eval_helpers_intra import compute_global_depth_buffer, project_part_visible  # noqa: F401
 from .mask_utils import load_and_prepare_masks, load_mask, mask_parts_from_image  # noqa: F401
 from .camera_geometry import look_at_rotation, project  # noqa: F401
-from .deformation_estimation import build_deformed_grid, deform_coords, deform_part, evaluate_part_deform  # noqa: F401
+from .deformation_estimation import (build_deformed_grid, deform_coords, deform_part, evaluate_part_deform,  # noqa: F401
+                                     evaluate_part_deform_batch)
 from .config import INTERIOR_PARTS, MAX_DIM, PART_COLORS, PART_COLORS_NP  # noqa: F401
 from .projection_utils import project_colored_voxels  # noqa: F401
 from .voxel_carving_utils import (apply_colored_mask_to_voxel_grid, carve_voxel_grid_with_masks, extrude_from_surface,  # noqa: F401

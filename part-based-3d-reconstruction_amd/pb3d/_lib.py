@@ -28,6 +28,7 @@ _SIGNATURES = {
     "pb3d_destroy": [vp],
     "pb3d_device_info": [vp, C.c_char_p, C.c_int, intp, i64p],
     "pb3d_sync": [vp],
+    "pb3d_set_tuning": [vp, C.c_char_p, C.c_int],
     "pb3d_dev_alloc": [vp, C.c_size_t, C.POINTER(vp)],
     "pb3d_dev_free": [vp, vp],
     "pb3d_dev_memset": [vp, vp, C.c_int, C.c_size_t],
@@ -61,6 +62,9 @@ _SIGNATURES = {
     "pb3d_project_dev": [vp, vp, C.c_int, vp, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],
     "pb3d_project": [vp, vp, C.c_int, u8p, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, u8p],
     "pb3d_partwise_iou_dev": [vp, vp, vp, i64, u8p, C.c_int, i64p, i64p],
+    "pb3d_project_iou_batch_dev": [vp, vp, C.c_int, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp, u8p, C.c_int, i64p, i64p],
+    "pb3d_look_at_batch": [vp, vp, C.c_int, i64, C.c_int, dblp],
+    "pb3d_deform_iou_batch_dev": [vp, vp, i64, dblp, C.c_int, i64, i64, i64, vp, C.c_int, C.c_int, vp, u8p, i64p, i64p, i64p],
     "pb3d_depth_buffer_dev": [vp, vp, C.c_int, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],
     "pb3d_visible_mask_dev": [vp, vp, C.c_int, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, vp, C.c_int, C.c_int,
                               C.c_double, C.c_int, vp],
@@ -87,6 +91,13 @@ _SIGNATURES = {
     "pb3d_comm_info": [vp, intp, intp],
     "pb3d_allgather_dev": [vp, vp, vp, C.c_size_t],
     "pb3d_comm_destroy": [vp],
+    "pb3d_carve_mask_sharded_dev": [vp, vp, i64, i64, i64, C.c_int, vp, vp],
+    "pb3d_global_carve_sharded_dev": [vp, vp, vp, i64, i64, C.c_int, vp],
+    "pb3d_carve_labels_sharded_dev": [vp, vp, i64, i64, i64, vp, vp, u8p, C.c_int, vp],
+    "pb3d_rgb_to_label_dev": [vp, vp, i64, u8p, C.c_int, vp],
+    "pb3d_label_to_rgb_dev": [vp, vp, i64, u8p, C.c_int, vp],
+    "pb3d_global_carve_label_dev": [vp, vp, vp, i64, i64, C.c_int, vp],
+    "pb3d_part_carve_label_dev": [vp, vp, i64, i64, i64, vp, vp, intp, intp, C.c_int, vp],
     "pb3d_project_keys_dev": [vp, vp, C.c_int, vp, i64, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],
     "pb3d_project_resolve_keys_dev": [vp, vp, C.c_int, C.c_int, vp],
     "pb3d_allreduce_max_u64_dev": [vp, vp, C.c_size_t],
@@ -150,6 +161,11 @@ def ctx():
             check(load().pb3d_create(default_device(), C.byref(h)))
             _ctx = h
     return _ctx
+
+
+def set_tuning(name, value):
+    """Development knob of the process context (include/pb3d.h: pb3d_set_tuning); results never depend on it."""
+    check(load().pb3d_set_tuning(ctx(), name.encode(), int(value)))
 
 
 def reset():

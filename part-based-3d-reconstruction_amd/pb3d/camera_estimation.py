@@ -91,8 +91,56 @@ class CameraObjective:
         per = [(i / u) if u > 0 else 0.0 for i, u in zip(inter, uni)]
         return -np.mean(per)
 
+    # struct pb3d_camera of include/pb3d.h
+    _CAM = np.dtype([("R", np.float64, 9), ("cam", np.float64, 3), ("f", np.float64), ("cx", np.float64), ("cy", np.float64),
+                     ("prec", np.int32, 4)], align=True)
+
     def evaluate_batch(self, params):
-        return [self(p) for p in params]
+        """[obj(p) for p in params] with ONE projection launch, one IoU launch and one counter download for the whole list
+        (the random / coordinate stages of the aligner evaluate dozens of cameras around the current one).  Exactly the values
+        of the one-at-a-time path: the same point kernel per camera, the same integer counts, the same float64 mean."""
+        from .camera_geometry import look_at_rotation_batch
+        from .projection_utils import _promotes_to_f64
+        params = list(params)
+        K = len(params)
+        if K == 0:
+            return []
+        for p in params:
+            if (int(p.get("H", self.H)), int(p.get("W", self.W))) != (self.H, self.W):
+                raise ValueError("operands could not be broadcast together: projection and part image differ in size")
+        eyes = [np.asarray(p["cam_pos"]) for p in params]; tgts = [np.asarray(p["target"]) for p in params]
+        dts = {a.dtype for a in eyes} | {a.dtype for a in tgts}
+        cams = np.zeros(K, self._CAM)
+        if len(dts) == 1 and all(a.shape == (3,) for a in eyes) and all(a.shape == (3,) for a in tgts):
+            E = np.stack(eyes); T = np.stack(tgts)
+            cams["R"] = look_at_rotation_batch(E, T).reshape(K, 9)
+            cams["cam"] = E
+            t0 = int(np.result_type(self._pts_dtype, E.dtype) == np.float64)     # R has the cameras' dtype (float32 `up` is the narrowest operand)
+            t0s = [t0] * K
+        else:                                                                    # mixed dtypes: the per-camera NumPy route decides everything
+            from .projection_utils import camera_args
+            t0s = []
+            for k, p in enumerate(params):
+                _, _, R, cam, prec = camera_args(np.zeros((1, 3), self._pts_dtype), p["cam_pos"], p["target"], p["f"], p["cx"], p["cy"])
+                cams["R"][k] = R.reshape(9); cams["cam"][k] = cam; t0s.append(int(prec[0]))
+        for k, p in enumerate(params):
+            tm = int(t0s[k] or _promotes_to_f64(p["f"]))
+            cams["prec"][k] = (t0s[k], tm, int(tm or _promotes_to_f64(p["cx"])), int(tm or _promotes_to_f64(p["cy"])))
+            cams["f"][k] = float(p["f"]); cams["cx"][k] = float(p["cx"]); cams["cy"][k] = float(p["cy"])
+        P = len(self._colors)
+        inter = np.zeros((K, P), np.int64); uni = np.zeros((K, P), np.int64)
+        _lib.check(_lib.load().pb3d_project_iou_batch_dev(
+            _lib.ctx(), None if not self.n else C.c_void_p(self._d_pts.ptr), self._pf64, None if not self.n else C.c_void_p(self._d_cols.ptr),
+            self.n, cams.ctypes.data_as(C.c_void_p), K, self.H, self.W, C.c_void_p(self._d_seg.ptr), _lib.p_u8(self._colors), P,
+            inter.ctypes.data_as(_lib.i64p), uni.ctypes.data_as(_lib.i64p)))
+        self.last_counts = (inter, uni)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            per = np.where(uni > 0, inter / uni, 0.0)
+        if 0 < P < 8:
+            # fewer than 8 addends: NumPy's reduction is the plain left-to-right sum whichever axis order its iterator
+            # picks, so the row-wise mean of the matrix has the bits of np.mean(list) per camera
+            return list(-(per.mean(axis=1)))
+        return [-np.mean(row) for row in per] if P else [-np.mean([]) for _ in range(K)]
 
     def projection(self):
         """the image of the last evaluation (H,W,3)"""

@@ -15,7 +15,7 @@ from .camera_estimation import compute_partwise_iou
 from .projection_utils import project_colored_voxels
 from .voxel_utils import get_voxel_points_by_parts
 
-__all__ = ["deform_coords", "deform_part", "evaluate_part_deform", "build_deformed_grid"]
+__all__ = ["deform_coords", "deform_part", "evaluate_part_deform", "evaluate_part_deform_batch", "build_deformed_grid"]
 
 
 def _scalars(image_shape, voxel_shape, deform):
@@ -68,6 +68,47 @@ def evaluate_part_deform(voxel_grid, part_labels, part, deform, image, cam_param
                                   cam_params["f"], cam_params["cx"], cam_params["cy"], H=image.shape[0], W=image.shape[1])
     per, _ = compute_partwise_iou(proj, image, {part: part_labels[part]})
     return proj, float(per[part])
+
+
+def evaluate_part_deform_batch(voxel_grid, part_labels, part, deforms, image, cam_params, stride=1):
+    """[evaluate_part_deform(...)[1] for deform in deforms] -- the IoU of every deform tuple of a grid search (the loop the
+    reference sketches at :148-258, `project_fast` with its point stride) -- with the part's points, the image and the camera
+    resident and ONE pair of launches for the whole list.  Returns (ious, nvalid): ious[k] is the float the one-at-a-time
+    path returns; nvalid[k] == 0 marks tuples whose deformed voxels all leave the grid (upstream prints a notice and has no
+    IoU; the entry is 0.0)."""
+    from . import device as dev
+    from .camera_estimation import CameraObjective
+    from .projection_utils import camera_args
+    grid = _lib.as_u8(voxel_grid, "voxel_grid")
+    img = _lib.as_u8(image, "image")
+    H, W = img.shape[:2]
+    A0, A1, A2 = grid.shape[:3]
+    deforms = list(deforms)
+    K = len(deforms)
+    coords, colors = get_voxel_points_by_parts(grid, part_labels, [part])
+    coords = np.ascontiguousarray(coords[::stride]); colors = colors[::stride]
+    if K == 0:
+        return [], np.zeros(0, np.int64)
+    if len(coords) == 0:
+        raise ValueError("cannot deform an empty point set")
+    d5 = np.ascontiguousarray([_scalars((H, W), (A0, A1, A2), d) for d in deforms], np.float64).reshape(K, 5)
+    # coords_def.astype(np.float32) is what upstream projects: float32 points, the camera's own dtypes
+    _, _, R, cam, prec = camera_args(np.zeros((1, 3), np.float32), cam_params["cam_pos"], cam_params["target"], cam_params["f"],
+                                     cam_params["cx"], cam_params["cy"])
+    c = np.zeros(1, CameraObjective._CAM)
+    c["R"][0] = R.reshape(9); c["cam"][0] = cam; c["f"][0] = float(cam_params["f"]); c["cx"][0] = float(cam_params["cx"])
+    c["cy"][0] = float(cam_params["cy"]); c["prec"][0] = list(prec)
+    color = np.ascontiguousarray(np.asarray(part_labels[part]).astype(np.uint8))
+    inter = np.zeros(K, np.int64); uni = np.zeros(K, np.int64); nvalid = np.zeros(K, np.int64)
+    d_pts = dev.from_numpy(coords); d_img = dev.from_numpy(img)
+    try:
+        _lib.check(_lib.load().pb3d_deform_iou_batch_dev(_lib.ctx(), C.c_void_p(d_pts.ptr), len(coords), _lib.p_dbl(d5), K, A0, A1, A2,
+                                                         c.ctypes.data_as(C.c_void_p), H, W, C.c_void_p(d_img.ptr), _lib.p_u8(color),
+                                                         inter.ctypes.data_as(_lib.i64p), uni.ctypes.data_as(_lib.i64p),
+                                                         nvalid.ctypes.data_as(_lib.i64p)))
+    finally:
+        d_pts.free(); d_img.free()
+    return [float(i / u) if (u > 0 and v > 0) else 0.0 for i, u, v in zip(inter, uni, nvalid)], nvalid
 
 
 def build_deformed_grid(voxel_grid, part_labels, saved_params, image_shape):

@@ -1,0 +1,158 @@
+"""The 1-byte LABEL form of semantic grids and masks (row N3, device half).
+
+A semantic grid holds only black and the colours of the part palette (reference utils/config.py:29-43; the masks that paint
+it come from reference utils/mask_utils.py:14-87), so one byte per voxel says everything: label 0 <-> (0,0,0), label k <->
+palette[k-1].  The carve path runs on label volumes at a third of the traffic, a multi-GPU run reassembles labels (1 B/voxel
+over xGMI instead of 3), and `label_to_rgb` of any result equals, byte for byte, what the RGB entry points return.
+
+    pal = Palette.from_part_colors(pb3d.PART_COLORS)            # name -> label, (n,3) colours
+    lab_mask = pal.mask_to_labels(semantic_mask)                # (H,W) uint8
+    grid = global_carve_labels(binary_mask, lab_mask)           # (w,h,w) uint8 labels
+    grid = part_carve_labels(grid, lab_mask, group_jobs, pal)   # same jobs as part_carve
+    rgb = label_to_rgb(grid, pal)                               # == part_carve(global_carve(binary, semantic), semantic, group_jobs)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hostmem, _lib
+
+__all__ = ["Palette", "rgb_to_label", "label_to_rgb", "global_carve_labels", "part_carve_labels"]
+
+
+class Palette:
+    """An ordered set of distinct non-black colours; label k is colours[k-1], label 0 is black."""
+
+    def __init__(self, colors, names=None):
+        c = np.asarray(colors)
+        if c.ndim != 2 or c.shape[1] != 3 or np.any(c < 0) or np.any(c > 255):
+            raise ValueError("palette colours must be (n,3) with values in 0..255")
+        self.colors = np.ascontiguousarray(c.astype(np.uint8))
+        if len(self.colors) > 254:
+            raise ValueError("at most 254 colours")
+        keys = {tuple(int(v) for v in row) for row in self.colors}
+        if len(keys) != len(self.colors) or (0, 0, 0) in keys:
+            raise ValueError("palette colours must be distinct and non-black (black is label 0)")
+        self.names = list(names) if names is not None else [str(k + 1) for k in range(len(self.colors))]
+        if len(self.names) != len(self.colors):
+            raise ValueError("one name per colour")
+
+    @classmethod
+    def from_part_colors(cls, part_colors):
+        names = list(part_colors.keys())
+        return cls([part_colors[n] for n in names], names)
+
+    def __len__(self):
+        return len(self.colors)
+
+    def label_of(self, name):
+        return self.names.index(name) + 1
+
+    def table(self):
+        """(n+1, 3) uint8: row k is the colour of label k"""
+        return np.concatenate([np.zeros((1, 3), np.uint8), self.colors])
+
+    def mask_to_labels(self, mask_hw3):
+        """(H,W,3) palette image -> (H,W) labels (same kernel as the volumes; a 2-D image is a small volume)."""
+        m = _lib.as_u8(mask_hw3, "mask")
+        if m.ndim != 3 or m.shape[2] != 3:
+            raise ValueError("mask must be (H,W,3)")
+        return rgb_to_label(m, self)
+
+
+def _pal(palette):
+    return palette if isinstance(palette, Palette) else Palette(palette)
+
+
+def rgb_to_label(grid_rgb, palette):
+    """(..., 3) uint8 colours -> (...) uint8 labels; ValueError if a colour is neither black nor in the palette."""
+    from . import device as dev
+    pal = _pal(palette)
+    g = _lib.as_u8(grid_rgb, "grid")
+    if g.ndim < 1 or g.shape[-1] != 3:
+        raise ValueError("grid must end in an RGB axis")
+    nvox = g.size // 3
+    out = _hostmem.empty(g.shape[:-1], np.uint8)
+    if nvox == 0:
+        return out
+    d_in = dev.from_numpy(g); d_out = dev.DeviceBuffer(nvox)
+    try:
+        _lib.check(_lib.load().pb3d_rgb_to_label_dev(_lib.ctx(), C.c_void_p(d_in.ptr), nvox, _lib.p_u8(pal.colors), len(pal), C.c_void_p(d_out.ptr)))
+        return d_out.download(g.shape[:-1])
+    finally:
+        d_in.free(); d_out.free()
+
+
+def label_to_rgb(labels, palette):
+    """(...) uint8 labels -> (..., 3) uint8 colours."""
+    from . import device as dev
+    pal = _pal(palette)
+    lab = _lib.as_u8(labels, "labels")
+    if lab.size == 0:
+        return np.zeros(lab.shape + (3,), np.uint8)
+    d_in = dev.from_numpy(lab); d_out = dev.DeviceBuffer(lab.size * 3)
+    try:
+        _lib.check(_lib.load().pb3d_label_to_rgb_dev(_lib.ctx(), C.c_void_p(d_in.ptr), lab.size, _lib.p_u8(pal.colors), len(pal), C.c_void_p(d_out.ptr)))
+        return d_out.download(lab.shape + (3,))
+    finally:
+        d_in.free(); d_out.free()
+
+
+def global_carve_labels(binary_mask, label_mask, angle_interval=90):
+    """global_carve (reference utils/voxel_carving_utils.py:269-298) on labels: (w,h,w) uint8 whose expansion with the
+    palette is global_carve(binary_mask, palette_image_of(label_mask), angle_interval)."""
+    from . import device as dev
+    b = np.asarray(binary_mask)
+    if b.ndim != 2:
+        raise ValueError("binary_mask must be (h,w)")
+    h, w = b.shape
+    lm = _lib.as_u8(label_mask, "label_mask")
+    if lm.shape != (h, w):
+        raise ValueError(f"label mask shape {lm.shape} does not match (h,w)=({h},{w})")
+    if isinstance(angle_interval, (bool, np.bool_)) or not isinstance(angle_interval, (int, np.integer)) or angle_interval <= 0:
+        raise ValueError("angle_interval must be a positive integer")
+    d_b = dev.from_numpy(_lib.truth_u8(b)); d_l = dev.from_numpy(lm); d_out = dev.DeviceBuffer(max(1, w * h * w))
+    try:
+        _lib.check(_lib.load().pb3d_global_carve_label_dev(_lib.ctx(), C.c_void_p(d_b.ptr), C.c_void_p(d_l.ptr), h, w, int(min(angle_interval, 91)),
+                                                           C.c_void_p(d_out.ptr)))
+        return d_out.download((w, h, w))
+    finally:
+        for d in (d_b, d_l, d_out):
+            d.free()
+
+
+def part_carve_labels(label_grid, label_mask, group_jobs, palette):
+    """part_carve (reference utils/voxel_carving_utils.py:139-160) on labels.  group_jobs as upstream: [(part names, angle)];
+    the names are looked up in the palette."""
+    from . import device as dev
+    from .voxel_carving_utils import _mask_to_wh
+    pal = _pal(palette)
+    g = _lib.as_u8(label_grid, "label_grid")
+    if g.ndim != 3:
+        raise ValueError("label_grid must be (W,H,D)")
+    W, H, D = g.shape
+    lm = _lib.as_u8(label_mask, "label_mask")
+    nj = len(group_jobs)
+    msub = np.zeros((max(nj, 1), W, H), np.uint8); mcarve = np.zeros((max(nj, 1), W, H), np.uint8)
+    angles = (C.c_int * max(nj, 1))(); skip = (C.c_int * max(nj, 1))()
+    for j, (names, angle) in enumerate(group_jobs):
+        sel = np.isin(lm, [pal.label_of(n) for n in names])
+        skip[j] = 0 if sel.any() else 1
+        if angle <= 0 and not skip[j]:
+            raise ValueError("job angles must be positive")
+        angles[j] = min(int(angle), 91)
+        m = sel.T.astype(np.uint8)
+        if m.shape != (W, H):
+            raise ValueError(f"operands could not be broadcast together: mask {m.shape} vs grid ({W},{H})")
+        msub[j] = m
+        mcarve[j] = _mask_to_wh(m, W, H)
+    if g.size == 0:
+        return np.zeros_like(g)
+    d_g = dev.from_numpy(g); d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve); d_out = dev.DeviceBuffer(g.size)
+    try:
+        _lib.check(_lib.load().pb3d_part_carve_label_dev(_lib.ctx(), C.c_void_p(d_g.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr), angles,
+                                                         skip, nj, C.c_void_p(d_out.ptr)))
+        return d_out.download(g.shape)
+    finally:
+        for d in (d_g, d_ms, d_mc, d_out):
+            d.free()

@@ -525,12 +525,14 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
         for ai in (45, 30, 50):
             for g in (g_bin, g_full, g_one_big):
                 want = oracle.process_voxel_grid(g, m, ai)
-                for tile in ("64", "128"):         # the 64x64 / 32-plane and the 128x128 / 16-plane kernels (the library picks by size)
-                    os.environ["PB3D_ROTATE_TILE"] = tile
+                # the 64x64 / 32-plane, the 128x128 / 16-plane and (D % 16 == 0) the packed 256x256 / 8-plane kernels; the
+                # library picks by size
+                for tile in (64, 128, 256):
+                    pb3d_gpu._lib.set_tuning("rotate_tile", tile)
                     try:
                         got = pb3d_gpu.process_voxel_grid(g, m, ai)
                     finally:
-                        del os.environ["PB3D_ROTATE_TILE"]
+                        pb3d_gpu._lib.set_tuning("rotate_tile", 0)
                     assert np.array_equal(got, want), (W, H, D, ai, tile, int((got != want).sum()))
 
 
@@ -662,14 +664,17 @@ def test_full_size_process_grid_45_against_oracle_slab(pb3d_gpu, oracle):
     dev.synth_mask16(S, d_binary_wh=d_mwh)
     lab, binary, rgb = synth_host.mask16(S)                  # (H,W) images
     dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out, d_tmp)
-    os.environ["PB3D_ROTATE_TILE"] = "64"
-    try:
-        dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out64, d_tmp)
-    finally:
-        del os.environ["PB3D_ROTATE_TILE"]
-    dev.sync()
-    full = d_out.download((S, S, S)); full64 = d_out64.download((S, S, S))
-    assert np.array_equal(full, full64)
+    full = None
+    for tile in (64, 128):                                   # the default at this size is the packed 256-tile kernel
+        pb3d_gpu._lib.set_tuning("rotate_tile", tile)
+        try:
+            dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out64, d_tmp)
+        finally:
+            pb3d_gpu._lib.set_tuning("rotate_tile", 0)
+        dev.sync()
+        if full is None:
+            full = d_out.download((S, S, S))
+        assert np.array_equal(full, d_out64.download((S, S, S))), tile
     assert full.max() <= 1 and 0 < int(full.sum()) < nvox
     occ = d_occ.download((S, S, S))
     for y0 in (0, S // 2 - 1, S - 3):
@@ -802,3 +807,83 @@ def test_five_monuments_deformation_loop_m5(pb3d_gpu, mon):
         saved[part] = {"deform": c["deform"], "iou": iou}
     full = pb3d_gpu.build_deformed_grid(grid, PC, saved, meta["image_shape"])
     assert sha(full) == meta["deformed_grid_sha256"] and int(np.any(full > 0, -1).sum()) == meta["deformed_grid_occupied"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mon", ["Akbar", "Charminar"])
+def test_camera_objective_batched_equals_one_at_a_time(pb3d_gpu, oracle, mon):
+    """row N4: K cameras per launch (pb3d_project_iou_batch_dev + pb3d_look_at_batch) give exactly the values of the
+    one-camera path -- float64 slider cameras, float32 JSON cameras, NumPy-scalar f / cx (NumPy-2 promotion), cameras behind
+    the cloud, straight-down views -- and a few of them are pinned on the oracle's project + IoU."""
+    meta = json.load(open(os.path.join(GOLDEN, "n45_objective_zbuffer.json")))
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = pb3d_gpu.PART_COLORS
+    m = meta[f"objective_{mon}"]
+    front = np.load(os.path.join(GOLDEN, "f7_projection.npz"))[f"img_{mon}_front"]
+    seg = pb3d_gpu.mask_parts_from_image(front, PC, m["parts"])
+    pts, cols = pb3d_gpu.get_voxel_points_by_parts(grid, PC, m["parts"])
+    labels = {p: PC[p] for p in m["parts"]}
+    obj = pb3d_gpu.CameraObjective(pts, cols, seg, labels)
+    rng = np.random.default_rng(77)
+    t0 = m["trials"][0]
+    base = np.array(list(t0["cam_pos"]) + list(t0["target"]) + [t0["f"], t0["cx"], t0["cy"]], np.float64)
+    params = []
+    for k in range(150):
+        x = base + rng.normal(size=9) * np.array([20, 20, 20, 5, 5, 5, 15, 4, 4]) * (k % 5 == 0 and 10 or 1)
+        p = {"cam_pos": x[:3], "target": x[3:6], "f": x[6], "cx": x[7], "cy": x[8], "H": m["H"], "W": m["W"]}
+        if k % 7 == 1:
+            p["f"] = float(x[6]); p["cx"] = float(x[7]); p["cy"] = float(x[8])          # Python floats: weak scalars
+        params.append(p)
+    p32 = [{"cam_pos": p["cam_pos"].astype(np.float32), "target": p["target"].astype(np.float32), "f": float(p["f"]), "cx": float(p["cx"]),
+            "cy": float(p["cy"]), "H": m["H"], "W": m["W"]} for p in params[:60]]                # the JSON path of notebooks 2/3
+    p32[3]["f"] = np.float64(p32[3]["f"])                                                      # a float64 NumPy scalar widens the later stages
+    p32[4]["cam_pos"] = p32[4]["target"] + np.array([0, 50, 0], np.float32)                    # looking straight down: the alternative up vector
+    for plist in (params, p32, params[:1], []):
+        got = obj.evaluate_batch(plist)
+        assert got == [obj(p) for p in plist]
+        assert all(type(a) is type(b) for a, b in zip(got, [obj(p) for p in plist[:3]]))
+    mixed = [params[0], p32[0], params[1]]                                                      # mixed dtypes in one list: per-camera NumPy route
+    assert obj.evaluate_batch(mixed) == [obj(p) for p in mixed]
+    fixture = [{"cam_pos": np.array(t["cam_pos"]), "target": np.array(t["target"]), "f": t["f"], "cx": t["cx"], "cy": t["cy"]} for t in m["trials"]]
+    assert obj.evaluate_batch(fixture) == [t["neg_iou"] for t in m["trials"]]                  # the reference's own values
+    for p in (params[0], params[5], p32[2], p32[3]):                                            # the oracle's own projection + IoU
+        proj = oracle.project_colored_voxels(pts, cols, p["cam_pos"], p["target"], p["f"], p["cx"], p["cy"], m["H"], m["W"])
+        _, mean_iou = oracle.compute_partwise_iou(proj, seg, labels)
+        assert obj.evaluate_batch([p])[0] == -mean_iou
+    obj.close()
+    # more than 8 parts: the mean takes NumPy's 8-accumulator path -- still the same bits as the single-camera route
+    names = list(PC.keys())
+    pts, cols = pb3d_gpu.get_voxel_points_by_parts(grid, PC, names)
+    obj = pb3d_gpu.CameraObjective(pts, cols, front, {n: PC[n] for n in names})
+    assert obj.evaluate_batch(params[:20]) == [obj(p) for p in params[:20]]
+    obj.close()
+
+
+@pytest.mark.gpu
+def test_deform_tuples_batched_equals_one_at_a_time(pb3d_gpu):
+    """row N4, deformation side: a grid of deform tuples through pb3d_deform_iou_batch_dev == evaluate_part_deform per tuple
+    (unique + bounds filter + projection + IoU), including tuples that push the whole part out of the grid."""
+    mon = "Akbar"
+    meta = json.load(open(os.path.join(GOLDEN, "m5_five_monuments_deformation.json")))[mon]
+    grid = np.load(os.path.join(GOLDEN, f"stored_{mon}_voxel_grid.npz"))["voxel_grid"]
+    PC = pb3d_gpu.PART_COLORS
+    cam = _cams(mon)["front"]
+    pts, cols = pb3d_gpu.get_voxel_points_by_parts(grid, PC, list(PC.keys()))
+    H, W = meta["image_shape"]
+    image = pb3d_gpu.project_colored_voxels(pts, cols, cam["cam_pos"], cam["target"], cam["f"], cam["cx"], cam["cy"], H, W)
+    for part, c in list(meta["cases"].items())[:2]:
+        deforms = [c["deform"]]
+        for sy in (0.8, 1.0, 1.2):
+            for sxz in (0.9, 1.1):
+                for dy in (-60.0, 0.0, 35.0):
+                    for dxz in (-20.0, 0.0, 60.0):
+                        deforms.append({"scale_y": sy, "shift_y": dy, "scale_xz": sxz, "shift_xz": dxz})
+        deforms.append({"scale_y": 1.0, "shift_y": 100000.0, "scale_xz": 1.0, "shift_xz": 0.0})        # everything leaves the grid
+        ious, nvalid = pb3d_gpu.evaluate_part_deform_batch(grid, PC, part, deforms, image, cam)
+        assert ious[0] == c["iou"]                                                              # the reference's own value
+        assert nvalid[-1] == 0 and ious[-1] == 0.0 and (nvalid > 0).sum() > 10
+        for k in range(0, len(deforms) - 1, 5):
+            if nvalid[k] == 0:                       # the whole part left the grid: upstream has nothing to project
+                assert ious[k] == 0.0 and len(pb3d_gpu.deform_part(grid, PC, part, deforms[k], image.shape[:2])[0]) == 0
+            else:
+                assert ious[k] == pb3d_gpu.evaluate_part_deform(grid, PC, part, deforms[k], image, cam)[1], (part, deforms[k])

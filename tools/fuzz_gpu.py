@@ -39,11 +39,10 @@ def main():
         m = rng.random((H, W)) < rng.uniform(0.2, 1.0)
         info = (n, W, H, D, ai)
         want = oracle.process_voxel_grid(g, m, ai)
-        for tile in ("64", "128", None):
-            if tile: os.environ["PB3D_ROTATE_TILE"] = tile
-            else: os.environ.pop("PB3D_ROTATE_TILE", None)
+        for tile in (64, 128, 256, 0):
+            pb3d._lib.set_tuning("rotate_tile", tile)
             ok("process", pb3d.process_voxel_grid(g, m, ai), want, info + (tile,))
-        os.environ.pop("PB3D_ROTATE_TILE", None)
+        pb3d._lib.set_tuning("rotate_tile", 0)
         col = pal[rng.integers(0, len(pal), (W, H, D))] * (rng.random((W, H, D, 1)) < dens).astype(np.uint8)
         ok("carve_rgb", pb3d.carve_voxel_grid_with_masks(col, m), oracle.carve_voxel_grid_with_masks(col, m), info)
         ok("carve_occ", pb3d.carve_voxel_grid_with_masks(g, m), oracle.carve_voxel_grid_with_masks(g, m), info)
