@@ -140,7 +140,19 @@ int pb3d_points_count(pb3d_ctx* ctx, const uint8_t* grid, int64_t A0, int64_t A1
         PB3D_REQUIRE(grid != nullptr, "pb3d_points_count: null grid");
         PB3D_TRY(up(ctx, 0, grid, nb, &dg));
     }
-    PB3D_TRY(pb3d_points_count_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, stride, n));
+    // One pass when the worst case fits a modest device buffer: the points are extracted while they are counted (decoupled
+    // look-back, csrc/points.hip) and pb3d_points_fill only downloads them -- the grid is read once instead of twice.
+    const i64 nvox = A0 * A1 * A2;
+    ctx->pts.extracted = false;
+    if (stride == 1 && nvox > 0 && (C == 3 || ncolors == 0) && (size_t)nvox * (12 + (size_t)C) <= ((size_t)8 << 30)) {
+        void *dp, *dc;
+        PB3D_TRY(pb3d_scratch(ctx, 1, (size_t)nvox * 3 * sizeof(float), &dp));
+        PB3D_TRY(pb3d_scratch(ctx, 3, (size_t)nvox * C, &dc));
+        PB3D_TRY(pb3d_points_extract_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, nvox, (float*)dp, (u8*)dc, n));
+        ctx->pts.extracted = true;
+    } else {
+        PB3D_TRY(pb3d_points_count_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, stride, n));
+    }
     ctx->pts.A0 = A0; ctx->pts.A1 = A1; ctx->pts.A2 = A2; ctx->pts.C = C;
     ctx->pts.ncolors = ncolors; ctx->pts.stride = stride; ctx->pts.n = *n;
     if (ncolors) memcpy(ctx->pts.colors, colors, (size_t)3 * ncolors);
@@ -156,10 +168,14 @@ int pb3d_points_fill(pb3d_ctx* ctx, int64_t n, float* pts, uint8_t* cols) {
     if (n == 0) return PB3D_OK;
     PB3D_REQUIRE(pts && cols, "pb3d_points_fill: null buffer");
     void *dp, *dc;
-    PB3D_TRY(pb3d_scratch(ctx, 1, (size_t)n * 3 * sizeof(float), &dp));
-    PB3D_TRY(pb3d_scratch(ctx, 3, (size_t)n * ctx->pts.C, &dc));
-    PB3D_TRY(pb3d_points_fill_dev(ctx, (const u8*)ctx->scratch[0], ctx->pts.A0, ctx->pts.A1, ctx->pts.A2, ctx->pts.C,
-                                  ctx->pts.colors, ctx->pts.ncolors, ctx->pts.stride, n, (float*)dp, (u8*)dc));
+    if (ctx->pts.extracted) {                    // already in scratch 1 / 3 (pb3d_points_count)
+        dp = ctx->scratch[1]; dc = ctx->scratch[3];
+    } else {
+        PB3D_TRY(pb3d_scratch(ctx, 1, (size_t)n * 3 * sizeof(float), &dp));
+        PB3D_TRY(pb3d_scratch(ctx, 3, (size_t)n * ctx->pts.C, &dc));
+        PB3D_TRY(pb3d_points_fill_dev(ctx, (const u8*)ctx->scratch[0], ctx->pts.A0, ctx->pts.A1, ctx->pts.A2, ctx->pts.C,
+                                      ctx->pts.colors, ctx->pts.ncolors, ctx->pts.stride, n, (float*)dp, (u8*)dc));
+    }
     PB3D_HIP(hipMemcpyAsync(pts, dp, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     return down(ctx, cols, dc, (size_t)n * ctx->pts.C);
 }

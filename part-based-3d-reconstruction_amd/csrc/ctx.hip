@@ -253,6 +253,7 @@ int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
         size_t padded = ((bytes ? bytes : 1) + 4095) & ~(size_t)4095;
         PB3D_HIP(hipMalloc(&ctx->scratch[slot], padded));
         ctx->scratch_bytes[slot] = padded;
+        ++ctx->scratch_gen;
     }
     *out = ctx->scratch[slot];
     return PB3D_OK;

@@ -14,7 +14,7 @@ typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-#define PB3D_NSCRATCH 24
+#define PB3D_NSCRATCH 28
 
 struct pb3d_event {
     hipEvent_t ev;
@@ -43,6 +43,7 @@ struct pb3d_ctx {
         int C, ncolors, stride;
         u8 colors[3 * 32];
         bool valid;
+        bool extracted;     // the points already sit in scratch 1 / 3 (single-pass extraction during the count)
     } pts;
     // state kept between pb3d_deform_count and pb3d_deform_fill
     struct {
@@ -50,6 +51,15 @@ struct pb3d_ctx {
         i64 X, Y, Z, n;
         bool valid;
     } deform;
+    // tables of the last generic-angle step (csrc/rotate.hip: launch_table_step) -- reused when the next step has the same key
+    struct RotCache {
+        int kind;               // 0: nothing cached
+        i64 W, H, D;
+        void* cells;
+        u64 gen;                // scratch_gen when the tables were built
+        double p[8];
+    } rot_cache;
+    u64 scratch_gen;            // bumped whenever ANY scratch slot is reallocated (cached tables in other slots may have moved)
     // RCCL (loaded lazily with dlopen; see comm.hip)
     void* rccl_lib;
     void* rccl_comm;

@@ -266,17 +266,34 @@ __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ g
 // in output order.  Phase 2: the block writes the compacted points and colours; coordinates come from the block's
 // base (a0,a1,a2) plus the local index with exact multiply-high divisions (no integer divide in the loop), colour
 // bytes leave as whole dwords cut out of two neighbouring 24-bit records (C == 1: four one-byte records per dword).
-template <int C>
+// SINGLE = true: the one-pass form for resident callers (pb3d_points_extract_dev).  There is no count pass and no scanned
+// offset table: a workgroup takes a ticket (its place in the output order: tickets are handed out in start order, so every
+// predecessor is running or finished), counts its own selection, publishes it, and obtains the sum of its predecessors by a
+// decoupled look-back over 64-bit status words (flag << 62 | value; flag 1 = this block's count, 2 = inclusive prefix).  A status
+// word is complete in itself, so relaxed agent-scope atomics are the whole protocol (no data is handed over behind it).
+struct ScanState {
+    unsigned long long* status;     // one word per block, zeroed before the launch
+    u32* ticket;                    // zeroed before the launch
+    i64* total;                     // out: number of selected voxels
+    i64 capacity;                   // rows the output buffers can take; blocks that would write past it write nothing
+};
+constexpr unsigned long long kFlagA = 1ull << 62, kFlagP = 2ull << 62, kValMask = (1ull << 62) - 1;
+
+template <int C, bool SINGLE>
 __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
-                                                       float* __restrict__ pts, u8* __restrict__ cols) {
+                                                       float* __restrict__ pts, u8* __restrict__ cols, ScanState st) {
     __shared__ u32 wsum[4];
     __shared__ u32 htab[256];
     __shared__ unsigned short lidx[kBlockVox];
     __shared__ u32 lrec[kBlockVox + 1];
+    __shared__ i64 sh_excl;
+    __shared__ u32 sh_bid;
     htab[threadIdx.x] = p.htab[threadIdx.x];
+    if (SINGLE && threadIdx.x == 0) sh_bid = atomicAdd(st.ticket, 1u);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const i64 base = (i64)blockIdx.x * kBlockVox;
+    const u32 bid = SINGLE ? sh_bid : blockIdx.x;
+    const i64 base = (i64)bid * kBlockVox;
     const i64 v0 = base + 16 * threadIdx.x;
     u32 w[12];
     const u32 bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
@@ -288,6 +305,31 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     u32 k = inc - c;
     for (int q = 0; q < wv; ++q) k += wsum[q];
     const u32 total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (SINGLE && wv == 0) {
+        // publish this block's count at once, then look back (wave 0, 64 predecessors per round, nearest predecessor in lane 0)
+        if (lane == 0) __hip_atomic_store(&st.status[bid], (bid == 0 ? kFlagP : kFlagA) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        i64 excl = 0;
+        i64 j = (i64)bid - 1;
+        while (j >= 0) {
+            const i64 idx = j - lane;
+            unsigned long long s = kFlagP;                        // lanes past block 0 contribute an empty prefix
+            if (idx >= 0) {
+                do { s = __hip_atomic_load(&st.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(s >> 62)) __builtin_amdgcn_s_sleep(1); } while (!(s >> 62));
+            }
+            const u64 pm = __ballot((s >> 62) == 2ull);
+            const int stop = pm ? __builtin_ctzll(pm) : 64;        // first lane that holds an inclusive prefix ends the walk
+            i64 v = lane <= stop ? (i64)(s & kValMask) : 0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            excl += v;
+            if (pm) break;
+            j -= 64;
+        }
+        if (lane == 0) {
+            if (bid != 0) __hip_atomic_store(&st.status[bid], kFlagP | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_excl = excl;
+            if (base + kBlockVox >= p.nlat) *st.total = excl + total;          // the last block knows the grand total
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if ((bits >> i) & 1u) {
@@ -299,7 +341,8 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
         }
     }
     __syncthreads();
-    const i64 out0 = block_off[blockIdx.x];
+    const i64 out0 = SINGLE ? sh_excl : block_off[blockIdx.x];
+    if (SINGLE && out0 + total > st.capacity) return;              // the caller's buffers are too small: write nothing past them
     // block base -> (b0, b1, b2); uniform, once per thread
     u32 b2, b1; i64 b0;
     if (p.nlat <= 0xffffffffll) {
@@ -445,15 +488,44 @@ int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64
                  "pb3d_points_fill: call pb3d_points_count first");
     const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
     if (fast16 && C == 1)
-        hipLaunchKernelGGL(k_points_fill16<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
-                           d_cols);
+        hipLaunchKernelGGL((k_points_fill16<1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
+                           d_cols, ScanState{});
     else if (fast16)
-        hipLaunchKernelGGL(k_points_fill16<3>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
-                           d_cols);
+        hipLaunchKernelGGL((k_points_fill16<3, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
+                           d_cols, ScanState{});
     else
         hipLaunchKernelGGL(k_points_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
                            d_cols);
     PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+
+int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C, const uint8_t* colors, int ncolors,
+                            int64_t capacity, float* d_pts, uint8_t* d_cols, int64_t* n) {
+    PB3D_REQUIRE(ctx != nullptr && n != nullptr && capacity >= 0, "pb3d_points_extract: bad argument");
+    *n = 0;
+    SelParams p;
+    PB3D_TRY(make_params(A0, A1, A2, C, colors, ncolors, 1, &p));
+    if (p.nlat == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid && (capacity == 0 || (d_pts && d_cols)), "pb3d_points_extract: null buffer");
+    PB3D_REQUIRE((C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0, "pb3d_points_extract: needs a 16-byte aligned grid (C == 3, or C == 1 without a colour set)");
+    const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
+    PB3D_REQUIRE(nb < (1ll << 31), "pb3d_points_extract: grid too large");
+    void* stv;
+    PB3D_TRY(pb3d_scratch(ctx, 24, (size_t)nb * sizeof(unsigned long long) + 64, &stv));   // not slot 9: a pending count -> fill pair keeps its offsets there
+    PB3D_HIP(hipMemsetAsync(stv, 0, (size_t)nb * sizeof(unsigned long long) + 64, ctx->stream));
+    ScanState st;
+    st.status = (unsigned long long*)((u8*)stv + 64);
+    st.ticket = (u32*)stv;
+    st.total = (i64*)((u8*)stv + 8);
+    st.capacity = capacity;
+    if (C == 1) hipLaunchKernelGGL((k_points_fill16<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st);
+    else hipLaunchKernelGGL((k_points_fill16<3, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st);
+    PB3D_CHECK_LAUNCH();
+    PB3D_HIP(hipMemcpyAsync(ctx->pinned, st.total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    *n = *(i64*)ctx->pinned;
     return PB3D_OK;
 }
 

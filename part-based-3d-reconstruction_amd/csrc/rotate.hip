@@ -80,34 +80,41 @@ __device__ __forceinline__ u32 sample(const u8* __restrict__ in, const Cell& c, 
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ in, u8* __restrict__ out,
                                                         const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D,
-                                                        int TY, const int* __restrict__ run_if, const u8* __restrict__ mask_src) {
+                                                        int TY, const int* __restrict__ run_if, const u8* __restrict__ mask_src,
+                                                        unsigned gx, unsigned gy, unsigned gz) {
     if (run_if && *run_if == 0) return;   // second pass of a table-driven step: only when a value > 1 was seen
+    // the (gx, gy, gz) block space is walked by however many workgroups were launched: the conditional second pass is launched
+    // with a small grid, so that skipping it costs microseconds
     const int lane = threadIdx.x & 63;
-    const i64 x = (i64)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const i64 z0 = ((i64)blockIdx.x * 64 + lane) * 4;
-    if (x >= W || z0 >= D) return;
-    const i64 y_beg = (i64)blockIdx.z * TY;
-    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
-    Cell c[4];
+    const u64 nblk = (u64)gx * gy * gz;
+    for (u64 b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const unsigned bx = (unsigned)(b % gx), by = (unsigned)((b / gx) % gy), bz = (unsigned)(b / ((u64)gx * gy));
+        const i64 x = (i64)by * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const i64 z0 = ((i64)bx * 64 + lane) * 4;
+        if (x >= W || z0 >= D) continue;
+        const i64 y_beg = (i64)bz * TY;
+        const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+        Cell c[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (z0 + q < D) c[q] = make_cell(p, x, z0 + q, W, D);
-        else { c[q].s0 = -1; c[q].s2 = 0; c[q].wx0 = c[q].wx1 = c[q].wz0 = c[q].wz1 = 0.0; }
-    }
-    for (i64 y = y_beg; y < y_end; ++y) {
-        const bool keep = mask_wh ? mask_wh[x * H + y] != 0 : true;  // wave-uniform
-        u32 r[4] = {0, 0, 0, 0};
-        if (keep) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = sample(in, c[q], y, H, D, mask_src);
+        for (int q = 0; q < 4; ++q) {
+            if (z0 + q < D) c[q] = make_cell(p, x, z0 + q, W, D);
+            else { c[q].s0 = -1; c[q].s2 = 0; c[q].wx0 = c[q].wx1 = c[q].wz0 = c[q].wz1 = 0.0; }
         }
-        u8* o = out + (x * H + y) * D + z0;
-        if (PACK) {
-            *(u32*)o = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-        } else {
+        for (i64 y = y_beg; y < y_end; ++y) {
+            const bool keep = mask_wh ? mask_wh[x * H + y] != 0 : true;  // wave-uniform
+            u32 r[4] = {0, 0, 0, 0};
+            if (keep) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (z0 + q < D) o[q] = (u8)r[q];
+                for (int q = 0; q < 4; ++q) r[q] = sample(in, c[q], y, H, D, mask_src);
+            }
+            u8* o = out + (x * H + y) * D + z0;
+            if (PACK) {
+                *(u32*)o = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (z0 + q < D) o[q] = (u8)r[q];
+            }
         }
     }
 }
@@ -321,17 +328,37 @@ __global__ __launch_bounds__(256, BITS_WAVES) void k_rotate_bits(const u8* __res
 // ------------------------------------------------------------------------------------------------
 struct CellRec { u32 src, lut; };      // src = s0 << 16 | s2 (0xffffffff: outside); lut bits 0..15 table, 16: x tap 1 used, 17: z tap 1 used
 
-__global__ __launch_bounds__(256) void k_rot_cells(RotParams p, i64 W, i64 D, CellRec* __restrict__ cells) {
+__global__ __launch_bounds__(256) void k_rot_cells(RotParams p, i64 W, i64 D, CellRec* __restrict__ cells, u32* __restrict__ lutmap) {
+    // lutmap (optional, 512 words, zeroed by the launcher): bit t is set when some cell's table bits 1..14 equal t -- a rotation
+    // produces about a dozen distinct tables, which lets the packed kernel keep a 4-bit index per cell (k_rot8_pack)
+    __shared__ u32 seen[512];
+    if (lutmap) { seen[threadIdx.x] = 0; seen[threadIdx.x + 256] = 0; __syncthreads(); }
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * D) return;
-    const i64 x = i / D, z = i - x * D;
-    const Cell c = make_cell(p, x, z, W, D);
-    CellRec r; r.src = 0xffffffffu; r.lut = 0;
-    if (c.s0 >= 0) {
-        r.src = ((u32)c.s0 << 16) | (u32)c.s2;
-        r.lut = lut_of(c) | (c.wx1 != 0.0 ? 1u << 16 : 0u) | (c.wz1 != 0.0 ? 1u << 17 : 0u);
+    u32 tbl = 0xffffffffu;
+    if (i < W * D) {
+        const i64 x = i / D, z = i - x * D;
+        const Cell c = make_cell(p, x, z, W, D);
+        CellRec r; r.src = 0xffffffffu; r.lut = 0;
+        if (c.s0 >= 0) {
+            r.src = ((u32)c.s0 << 16) | (u32)c.s2;
+            r.lut = lut_of(c) | (c.wx1 != 0.0 ? 1u << 16 : 0u) | (c.wz1 != 0.0 ? 1u << 17 : 0u);
+            tbl = (r.lut >> 1) & 0x3fffu;
+        }
+        cells[i] = r;
     }
-    cells[i] = r;
+    if (lutmap) {
+        // a wave holds a handful of distinct tables: one LDS atomic per distinct value, not per lane
+        u64 todo = __ballot(tbl != 0xffffffffu);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const u32 tv = (u32)__shfl((int)tbl, lead);
+            if ((int)(threadIdx.x & 63) == lead) atomicOr(&seen[tv >> 5], 1u << (tv & 31));
+            todo &= ~__ballot(tbl == tv);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 512; k += 256)         // a dozen distinct tables in all: after the first blocks nothing is new
+            if (seen[k] && (__hip_atomic_load(&lutmap[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & seen[k]) != seen[k]) atomicOr(&lutmap[k], seen[k]);
+    }
 }
 
 __device__ __forceinline__ u32 pperm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -886,12 +913,16 @@ constexpr int PLDS_DATA = 76 * 1024;                // packed footprint, one byt
 constexpr int PMAXUNITS = PLDS_DATA / 16;           // 16-voxel units
 constexpr int PUPT = (PMAXUNITS + PTHREADS - 1) / PTHREADS;   // units per thread (10)
 constexpr int PPARTS = 8;                           // set-up: 32 x-rows of a tile per workgroup
-constexpr size_t kPLds = (size_t)PLDS_DATA + PROWS * 4;
+constexpr int PNOROW = (int)0x80000000;
+constexpr size_t kPLds = (size_t)PLDS_DATA + (PROWS + 1) * 4 + 16 * 4;
+constexpr size_t kPLdsPair = (size_t)2 * PLDS_DATA + (PROWS + 1) * 4 + 16 * 4;
 
 struct PPart { int bb[4]; int rmin[PROWS], rmax[PROWS]; };
 struct PTile {
     int bx0, nrows, nunits, fits;
-    u32 btab[PROWS];                  // low 16: ustart[r] ; high 16 (signed): unit index such that 16 * it + c addresses (r + 1, s2)
+    u32 dict[16];                     // the step's distinct 14-bit tables (bits 1..14 of SciPy's result table), ascending; ndict <= 15
+    int ndict;
+    int atab[PROWS + 1];              // LDS byte of source voxel (row r, column s2) = atab[r] + s2 ; PNOROW: the row is not staged
     int start16[PROWS];               // first staged column of row r (multiple of 16)
     u32 voff[PMAXUNITS];              // voxel offset of unit i at plane 0: (bx0 + r) * H * D + start16[r] + 16 k
     unsigned short srow[PMAXUNITS];   // r of unit i
@@ -944,8 +975,11 @@ __global__ __launch_bounds__(PTHREADS) void k_rot8_parts(const CellRec* __restri
 }
 
 // per tile: merge the parts, lay the rows out in LDS, list the staging units
-__global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict__ parts, i64 H, i64 D, PTile* __restrict__ tiles) {
+__global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict__ parts, const u32* __restrict__ lutmap, i64 H, i64 D,
+                                                         PTile* __restrict__ tiles) {
     __shared__ int sb[2 + PPARTS];
+    __shared__ int dcount[PTHREADS / 64 + 1];
+    __shared__ u32 dict[16];
     __shared__ int lo[PROWS + 1], hi[PROWS + 1], ust[PROWS + 2];
     __shared__ int wsum[PTHREADS / 64];
     const int tid = threadIdx.x;
@@ -994,17 +1028,30 @@ __global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict
     if (tid <= PROWS) ust[tid] = base + inc - n_units;
     if (tid == PTHREADS - 1) ust[PROWS + 1] = base + inc;
     __syncthreads();
-    const int nunits = ust[PROWS + 1];
-    const bool fits = rows_fit && nunits <= PMAXUNITS;
-    if (tid == 0) { ti->bx0 = bx0; ti->nrows = nrows; ti->nunits = fits ? nunits : 0; ti->fits = (fits || nrows == 0) ? 1 : 0; }
-    if (tid < PROWS) {
-        const int r = tid;
-        // row r + 1 through row r's column index: 16 * nxt + (s2 - lo[r]) = 16 * ust[r + 1] + (s2 - lo[r + 1])
-        int nxt = ust[r];
-        if (hi[r] >= 0 && hi[r + 1] >= 0) nxt = ust[r + 1] + ((lo[r] - lo[r + 1]) >> 4);     // both multiples of 16: exact
-        ti->btab[r] = ((u32)ust[r] & 0xffffu) | ((u32)nxt << 16);
-        ti->start16[r] = lo[r];
+    // dictionary of the step's tables: word `tid` of the presence bitmap, set bits listed in ascending order (every tile block
+    // builds the same list; it is 512 words)
+    {
+        const u32 w = lutmap[tid];
+        const int cnt = __popc(w);
+        int pre = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o); if ((tid & 63) >= o) pre += v; }
+        if ((tid & 63) == 63) dcount[tid >> 6] = pre;
+        __syncthreads();
+        int dbase = 0;
+        for (int k = 0; k < (tid >> 6); ++k) dbase += dcount[k];
+        int pos = dbase + pre - cnt;
+        for (u32 m = w; m; m &= m - 1) { if (pos < 16) dict[pos] = (u32)(32 * tid + __builtin_ctz(m)); ++pos; }
+        if (tid == PTHREADS - 1) dcount[PTHREADS / 64] = dbase + pre;
+        __syncthreads();
     }
+    const int ndict = dcount[PTHREADS / 64];
+    const int nunits = ust[PROWS + 1];
+    const bool fits = rows_fit && nunits <= PMAXUNITS && ndict <= 15;
+    if (tid == 0) { ti->bx0 = bx0; ti->nrows = nrows; ti->nunits = fits ? nunits : 0; ti->fits = (fits || nrows == 0) ? 1 : 0; ti->ndict = ndict; }
+    if (tid < 16) ti->dict[tid] = tid < ndict ? dict[tid] : 0xffffffffu;
+    if (tid <= PROWS) ti->atab[tid] = hi[tid] >= 0 ? 16 * ust[tid] - lo[tid] : PNOROW;
+    if (tid < PROWS) ti->start16[tid] = lo[tid];
     if (fits) {
         for (int i = tid; i < nunits; i += PTHREADS) {            // unit i -> its row: the last r with ust[r] <= i
             int a = 0, b = PROWS;
@@ -1015,21 +1062,62 @@ __global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict
     }
 }
 
-// one dword per cell: footprint row | column within the row << 9 | table bits 1..14 << 18 ; all ones = outputs 0
-__global__ __launch_bounds__(256) void k_rot8_pack(const CellRec* __restrict__ cells, const PTile* __restrict__ tiles, i64 W, i64 D, int ntz,
-                                                   u32* __restrict__ recs) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * D) return;
-    const i64 x = i / D, z = i - x * D;
-    const PTile* ti = tiles + (x / PT) * ntz + z / PT;
-    const CellRec c = cells[i];
-    u32 rec = 0xffffffffu;
-    if (c.src != 0xffffffffu && ti->fits) {
-        const int r = (int)(c.src >> 16) - ti->bx0;
-        const int col = (int)(c.src & 0xffffu) - ti->start16[r];
-        rec = (u32)r | ((u32)col << 9) | (((c.lut >> 1) & 0x3fffu) << 18);
+// One 16-byte record per run of 16 cells along z (the unit a thread of the tile kernel evaluates): consecutive cells of a run
+// step through the footprint by (-1 or 0, 0 or +1) -- a rotation by 0..90 degrees moves the source row down and the source
+// column up along +z -- so a run is its first cell's position, two step bits per cell and a 4-bit table index per cell:
+//   w0 = footprint row r0 | source column s2 << 9 (of the first cell that is not void) ; w1 bit i = row step into cell i, bit 16 + i =
+//   column step into cell i ; w2, w3 = 4-bit dictionary index of cells 0..7, 8..15 (15 = void: outputs 0, takes no step)
+// 1 byte per cell instead of a position + table dword: a thread keeps its 8 runs in registers for all its passes.  A run that
+// does not follow the pattern (or a tile that does not fit) marks the tile unfit: the step is then redone by the arithmetic
+// kernel (device-side flag).
+struct RunRec { u32 w0, w1, w2, w3; };
+
+// one lane per cell, 16 consecutive lanes per run
+__global__ __launch_bounds__(256) void k_rot8_pack(const CellRec* __restrict__ cells, PTile* __restrict__ tiles, i64 W, i64 D, int ntz,
+                                                   RunRec* __restrict__ runs) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;       // cell index x * D + z (D % 16 == 0: a run never straddles rows)
+    const bool inside = i < W * D;
+    const i64 x = inside ? i / D : 0, z = inside ? i - x * D : 0;
+    PTile* ti = tiles + (x / PT) * ntz + z / PT;
+    const int c = (int)(threadIdx.x & 15);                          // position in the run
+    const bool tile_ok = inside && ti->fits;
+    bool live = false, bad = false;
+    int r = 0, s2 = 0;
+    u32 k = 15;
+    if (tile_ok) {
+        const CellRec cr = cells[i];
+        if (cr.src != 0xffffffffu) {
+            live = true;
+            r = (int)(cr.src >> 16) - ti->bx0;
+            s2 = (int)(cr.src & 0xffffu);
+            const u32 t = (cr.lut >> 1) & 0x3fffu;
+            const int nd = ti->ndict;
+            k = 0;
+            while ((int)k < nd && ti->dict[k] != t) ++k;
+            if ((int)k >= nd) { bad = true; k = 15; }
+        }
     }
-    recs[i] = rec;
+    // the run's live cells must be one contiguous block; steps are taken between consecutive live cells
+    const u64 lv = __ballot(live);
+    const u32 seg = (u32)(lv >> (threadIdx.x & 48)) & 0xffffu;
+    const int first = seg ? __builtin_ctz(seg) : 0;
+    if (seg && (((seg >> first) + 1u) & (seg >> first)) != 0u) bad = true;
+    const int pr = __shfl_up(r, 1), ps2 = __shfl_up(s2, 1);
+    u32 w1 = 0;
+    if (live && c > first) {
+        const int dr = pr - r, dc = s2 - ps2;
+        if (dr < 0 || dr > 1 || dc < 0 || dc > 1) bad = true;
+        w1 = ((u32)(dr & 1) << c) | ((u32)(dc & 1) << (16 + c));
+    }
+    u32 w0 = (live && c == first) ? ((u32)r | ((u32)s2 << 9)) : 0u;
+    u32 w2 = c < 8 ? k << (4 * c) : 0u, w3 = c >= 8 ? k << (4 * (c - 8)) : 0u;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        w0 |= (u32)__shfl_xor((int)w0, o); w1 |= (u32)__shfl_xor((int)w1, o);
+        w2 |= (u32)__shfl_xor((int)w2, o); w3 |= (u32)__shfl_xor((int)w3, o);
+    }
+    if (__ballot(bad) && bad) ti->fits = 0;                         // benign race: every writer stores 0
+    if (inside && c == 0) { RunRec rec = {w0, w1, w2, w3}; runs[i >> 4] = rec; }
 }
 
 __device__ __forceinline__ u32 lut_apply14(u32 lut14, u32 t00, u32 t01, u32 t10, u32 t11) {
@@ -1062,15 +1150,22 @@ __device__ __forceinline__ u32 mask8(const u8* __restrict__ p, int np) {
     return bits;
 }
 
-template <bool SRCMASK>
-__global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
-                                                               const u32* __restrict__ recs, const PTile* __restrict__ tiles, i64 W, i64 H, i64 D,
+// PAIR = false: 512 threads, one footprint buffer, two workgroups per CU (the hardware decides how their phases fall together).
+// PAIR = true : 1024 threads = two wave groups with a footprint buffer each, ONE workgroup per CU; the groups work on alternate
+//               passes of the plane chunk and are offset by one phase, so that between any two workgroup barriers one group
+//               STAGES (HBM reads, little VALU) while the other EVALUATES (LDS + VALU + stores) -- the pairing is by construction.
+template <bool SRCMASK, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * PTHREADS : PTHREADS, PAIR ? 1 : 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
+                                                               const RunRec* __restrict__ runs, const PTile* __restrict__ tiles, i64 W, i64 H, i64 D,
                                                                int TY, int ntz, int ntiles, int nchunks, int* __restrict__ big_flag,
-                                                               const u8* __restrict__ mask_src, int abl) {
-    extern __shared__ __attribute__((aligned(16))) u8 plds[];
-    u32* btab = (u32*)(plds + PLDS_DATA);
+                                                               const u8* __restrict__ mask_src, int abl, int skew16) {
+    extern __shared__ __attribute__((aligned(16))) u8 plds_all[];
+    int* atab = (int*)(plds_all + (PAIR ? 2 : 1) * PLDS_DATA);   // PROWS + 1 entries
+    u32* dict = (u32*)(atab + PROWS + 1);              // 16 entries
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x;
+    const int group = PAIR ? (int)(threadIdx.x >> 9) : 0;           // wave-uniform
+    const int tid = (int)(threadIdx.x & (PTHREADS - 1));
+    u8* plds = plds_all + (size_t)group * PLDS_DATA;
     const int slot = (int)(blockIdx.x >> 3);
     const int t = slot % ntiles;
     const int chunk = (slot / ntiles) * 8 + (int)(blockIdx.x & 7u);
@@ -1082,95 +1177,184 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
     const int nunits = ti->nunits;
     const i64 bx0 = ti->bx0;
-    for (int i = tid; i < PROWS; i += PTHREADS) btab[i] = ti->btab[i];
-    u32 uvoff[PUPT], umrow[PUPT];
+    if (group == 0) {
+        for (int i = tid; i <= PROWS; i += PTHREADS) atab[i] = ti->atab[i];
+        if (tid < 16) dict[tid] = ti->dict[tid];
+    }
+    u32 uvoff[PUPT], usrow[(PUPT + 1) / 2];           // usrow: footprint row of unit j, two per register (source-mask form only)
+#pragma unroll
+    for (int j = 0; j < (PUPT + 1) / 2; ++j) usrow[j] = 0;
 #pragma unroll
     for (int j = 0; j < PUPT; ++j) {
         const int i = tid + PTHREADS * j;
         uvoff[j] = i < nunits ? ti->voff[i] : 0xffffffffu;
-        umrow[j] = (SRCMASK && i < nunits) ? (u32)((bx0 + ti->srow[i]) * H) : 0u;
+        if (SRCMASK && i < nunits) usrow[j >> 1] |= (u32)ti->srow[i] << (16 * (j & 1));
+    }
+    // This thread's 8 runs of 16 cells, in registers for the whole life of the workgroup.  A wave holds 16 consecutive x-rows
+    // (lane & 15) of 4 neighbouring runs (lane >> 4): run slot q of wave w is row group (8 q + w) >> 2, run group (8 q + w) & 3.
+    // Lanes of one row group walk their runs CYCLICALLY from a per-row start phase (skew), so that at every step the 16 lanes of a
+    // run group sit on an output diagonal whose source voxels share one footprint row: their tap reads fall into a few consecutive
+    // LDS dwords instead of 16 unrelated ones (bank conflicts were what bounded the evaluation).
+    const int wv_ = tid >> 6, jrow = tid & 15, krun = (tid >> 4) & 3;
+    const int phase = ((jrow * skew16) >> 4) & 15;
+    u32x4 run[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int combo = 8 * k + wv_;
+        const i64 x = x0 + 16 * (combo >> 2) + jrow, z = z0 + 16 * (4 * (combo & 3) + krun);
+        run[k] = (u32x4)(0u, 0u, 0xffffffffu, 0xffffffffu);
+        if (x < W && z < D) run[k] = *(const u32x4*)(runs + x * (D / 16) + (z >> 4));
     }
     __syncthreads();
     u32 hib = 0;
-    const int zc = 16 * (tid & 15);                    // this thread's 16-cell run inside a tile row
-    for (i64 yg = y_beg; yg < y_end; yg += 8) {
+    auto stage = [&](i64 yg) {
         const int np = (int)(y_end - yg < 8 ? y_end - yg : 8);
-        // ---- stage the footprint of 8 planes: 16 voxels x 8 planes per unit; the next unit's loads are issued before this one is packed
-        u32x4 d[2][8];
-        auto load_unit = [&](u32x4 (&dd)[8], int j) {
+        // ---- stage the footprint of 8 planes: 16 voxels x 8 planes per unit, loaded as two halves of 4 planes; the next half's loads
+        //      are issued before this one is packed (8 x 16 B in flight per lane, 128 KB per CU)
+        u32x4 d[2][4];
+        auto load_half = [&](u32x4 (&dd)[4], int hh) {           // hh = 2 * unit + half
+            const int j = hh >> 1, q0 = 4 * (hh & 1);
             const u32 voff = uvoff[j];
             u32 msrc = 0xffu;
-            if (SRCMASK && voff != 0xffffffffu) msrc = mask8(mask_src + umrow[j] + yg, np);
+            if (SRCMASK && voff != 0xffffffffu) msrc = mask8(mask_src + (u32)((bx0 + ((usrow[j >> 1] >> (16 * (j & 1))) & 0xffffu)) * H) + yg, np);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const u8* pb = in + (yg + q) * D;              // uniform
+            for (int q = 0; q < 4; ++q) {
+                const u8* pb = in + (yg + q0 + q) * D;         // uniform
                 dd[q] = (u32x4)(0u);
-                if (voff != 0xffffffffu && q < np && ((msrc >> q) & 1u)) dd[q] = *(const u32x4*)(pb + voff);
+                if (voff != 0xffffffffu && q0 + q < np && ((msrc >> (q0 + q)) & 1u)) dd[q] = *(const u32x4*)(pb + voff);
             }
         };
-        if (!(abl & 2)) load_unit(d[0], 0);
+        if (!(abl & 2)) load_half(d[0], 0);
+        u32x4 wv = (u32x4)(0u);
 #pragma unroll
-        for (int j = 0; j < PUPT; ++j) {
+        for (int hh = 0; hh < 2 * PUPT; ++hh) {
             if (abl & 2) break;
-            if (j + 1 < PUPT) load_unit(d[(j + 1) & 1], j + 1);
+            if (hh + 1 < 2 * PUPT) load_half(d[(hh + 1) & 1], hh + 1);
+            const int j = hh >> 1, q0 = 4 * (hh & 1);
             if (uvoff[j] != 0xffffffffu) {
-                u32x4 wv = (u32x4)(0u);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const u32x4 dd = d[j & 1][q];
-                    wv.x |= (dd.x & 0x01010101u) << q; wv.y |= (dd.y & 0x01010101u) << q;
-                    wv.z |= (dd.z & 0x01010101u) << q; wv.w |= (dd.w & 0x01010101u) << q;
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 dd = d[hh & 1][q];
+                    wv.x |= (dd.x & 0x01010101u) << (q0 + q); wv.y |= (dd.y & 0x01010101u) << (q0 + q);
+                    wv.z |= (dd.z & 0x01010101u) << (q0 + q); wv.w |= (dd.w & 0x01010101u) << (q0 + q);
                     hib |= dd.x | dd.y | dd.z | dd.w;
                 }
-                *(u32x4*)(plds + 16 * (tid + PTHREADS * j)) = wv;
+                if (hh & 1) { *(u32x4*)(plds + 16 * (tid + PTHREADS * j)) = wv; wv = (u32x4)(0u); }
             }
         }
-        __syncthreads();
-        // ---- evaluate: 4 quarter passes of 64 x-rows; a thread owns two 16-cell runs (rows xa and xa + 32) per quarter
+    };
+    auto evaluate = [&](i64 yg) {
+        const int np = (int)(y_end - yg < 8 ? y_end - yg : 8);
+        // ---- evaluate the thread's 8 runs; the run registers rotate by one per slot so that the loop body always names run[0] (no
+        //      dynamic register indexing), and are back in place after the eighth
 #pragma unroll 1
-        for (int qq = 0; qq < 4; ++qq) {
+        for (int qq = 0; qq < 8; ++qq) {
             if (abl & 1) break;
+            // A run is decoded branch-free, four cells at a time, starting at cell `phase` and wrapping: the position of the start
+            // cell is the run's base plus the row / column steps below it (two popcounts), then every cell takes its own step -- or
+            // returns to the base when the walk wraps to cell 0.  Per group: all row-table reads, then the 16 tap reads, then the
+            // four table evaluations (an LDS round trip per group, not per cell).
+            const u32x4 rec = run[0];
+            const int r0 = (int)(rec.x & 511u);
+            const u32 s20 = rec.x >> 9, drb = rec.y & 0xffffu, dcb = rec.y >> 16;
+            const u32 below = (2u << phase) - 2u;                                       // steps into cells 1 .. phase
+            int r = r0 - __popc(drb & below);
+            u32 s2 = s20 + (u32)__popc(dcb & below);
+            const unsigned long long kw = ((unsigned long long)rec.w << 32) | rec.z;    // 16 x 4-bit table indices
+            u32 G0 = 0, G1 = 0, G2 = 0, G3 = 0;
+            int ci = phase;
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                int rc[4]; u32 sc[4], kc[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const i64 x = x0 + 64 * qq + 32 * h + (tid >> 4);
-                const i64 z = z0 + zc;
-                if (x >= W || z >= D) continue;
-                u32 rec[16];
-                const u32x4* rp = (const u32x4*)(recs + x * D + z);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { const u32x4 v = rp[k]; rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w; }
-                const u32 mbits = mask_wh ? mask8(mask_wh + x * H + yg, np) : 0xffu;
-                u32 G[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    u32 R[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const u32 rc = rec[4 * i + c];
-                        R[c] = 0;
-                        if (rc != 0xffffffffu) {
-                            const u32 tb = btab[rc & 511u], col = (rc >> 9) & 511u;
-                            const u32 o0 = ((tb & 0xffffu) << 4) + col;
-                            const u32 o1 = (u32)(((int)tb >> 16) * 16) + col;
-                            R[c] = lut_apply14(rc >> 18, plds[o0], plds[o0 + 1], plds[o1], plds[o1 + 1]);
-                        }
+                for (int c = 0; c < 4; ++c) {
+                    if (i | c) {                                                         // the start cell's position is already set
+                        ci = (ci + 1) & 15;
+                        const bool wrap = ci == 0;
+                        r = wrap ? r0 : r - (int)((drb >> ci) & 1u);                    // void cells carry no step bits
+                        s2 = wrap ? s20 : s2 + ((dcb >> ci) & 1u);
                     }
-                    const u32 l01 = pperm(R[1], R[0], 0x0c0c0400u), l23 = pperm(R[3], R[2], 0x0c0c0400u);   // byte 0 of each pair
-                    G[i] = l01 | (l23 << 16);
+                    kc[c] = (u32)(kw >> (4 * ci)) & 15u;
+                    rc[c] = r; sc[c] = s2;
                 }
+                int a0[4], a1[4]; u32 lt[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { a0[c] = atab[rc[c]]; a1[c] = atab[rc[c] + 1]; lt[c] = dict[kc[c]]; }
+                u32 tp[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool live = kc[c] != 15u;
+                    const u32 o0 = live ? (u32)a0[c] + sc[c] : 0u;
+                    const u32 o1 = (live && a1[c] != PNOROW) ? (u32)a1[c] + sc[c] : o0;     // unused x tap: any staged byte will do
+                    tp[c][0] = plds[o0]; tp[c][1] = plds[o0 + 1]; tp[c][2] = plds[o1]; tp[c][3] = plds[o1 + 1];
+                }
+                u32 R[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    R[c] = lut_apply14(lt[c], tp[c][0], tp[c][1], tp[c][2], tp[c][3]);
+                    R[c] = kc[c] != 15u ? R[c] : 0u;
+                }
+                const u32 l01 = pperm(R[1], R[0], 0x0c0c0400u), l23 = pperm(R[3], R[2], 0x0c0c0400u);   // byte 0 of each pair
+                G0 = G1; G1 = G2; G2 = G3; G3 = l01 | (l23 << 16);                 // after four groups: bytes in WALK order
+            }
+            // walk order -> cell order: byte n of (G0..G3) belongs to cell (phase + n) & 15, i.e. rotate the 16 bytes left by `phase`
+            {
+                const u32 sh = (u32)(phase & 3);
+                // out dword m, byte b  <-  walk byte (4 m + b - phase) & 15
+                const u32 t0 = __builtin_amdgcn_alignbyte(G0, G3, 4u - sh), t1 = __builtin_amdgcn_alignbyte(G1, G0, 4u - sh),
+                          t2 = __builtin_amdgcn_alignbyte(G2, G1, 4u - sh), t3 = __builtin_amdgcn_alignbyte(G3, G2, 4u - sh);
+                const u32 u0 = sh ? t0 : G0, u1 = sh ? t1 : G1, u2 = sh ? t2 : G2, u3 = sh ? t3 : G3;    // alignbyte by 4 is not the identity
+                const int dq = phase >> 2;                                                       // whole dwords
+                G0 = dq == 0 ? u0 : (dq == 1 ? u3 : (dq == 2 ? u2 : u1));
+                G1 = dq == 0 ? u1 : (dq == 1 ? u0 : (dq == 2 ? u3 : u2));
+                G2 = dq == 0 ? u2 : (dq == 1 ? u1 : (dq == 2 ? u0 : u3));
+                G3 = dq == 0 ? u3 : (dq == 1 ? u2 : (dq == 2 ? u1 : u0));
+            }
+            const int combo = 8 * qq + wv_;
+            const i64 x = x0 + 16 * (combo >> 2) + jrow;
+            const i64 z = z0 + 16 * (4 * (combo & 3) + krun);
+            if (x < W && z < D) {
+                const u32 mbits = mask_wh ? mask8(mask_wh + x * H + yg, np) : 0xffu;
                 const u32 ooff = (u32)(x * H * D + z);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (q >= np) break;
                     const u32 keep = ((mbits >> q) & 1u) ? 0x01010101u : 0u;
-                    u32x4 r;
-                    r.x = (G[0] >> q) & keep; r.y = (G[1] >> q) & keep; r.z = (G[2] >> q) & keep; r.w = (G[3] >> q) & keep;
+                    u32x4 rr;
+                    rr.x = (G0 >> q) & keep; rr.y = (G1 >> q) & keep; rr.z = (G2 >> q) & keep; rr.w = (G3 >> q) & keep;
                     u8* pb = out + (yg + q) * D;                          // uniform
-                    *(u32x4*)(pb + ooff) = r;
+                    *(u32x4*)(pb + ooff) = rr;
                 }
             }
+            const u32x4 t0 = run[0];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) run[k] = run[k + 1];
+            run[7] = t0;
         }
-        __syncthreads();
+    };
+    if (!PAIR) {
+        for (i64 yg = y_beg; yg < y_end; yg += 8) {
+            stage(yg);
+            __syncthreads();
+            evaluate(yg);
+            __syncthreads();
+        }
+    } else {
+        // group g owns the passes g, g + 2, ... of the chunk; group 1 runs one phase behind group 0.  Every wave executes the same
+        // number of barriers: a phase is [one group stages | the other evaluates] between two of them.
+        const i64 npass = (y_end - y_beg + 7) / 8;
+        const i64 mine = (npass + 1 - group) / 2;               // passes of this group
+        const i64 phases = 2 * ((npass + 1) / 2) + ((npass & 1) ? 0 : 1);     // group 0: 2 * ceil(n/2); group 1: 1 + 2 * floor(n/2)
+        i64 done = 0;
+        if (group == 1) { __syncthreads(); ++done; }
+        for (i64 k = 0; k < mine; ++k) {
+            const i64 yg = y_beg + 8 * (group + 2 * k);
+            stage(yg);
+            __syncthreads(); ++done;
+            evaluate(yg);
+            __syncthreads(); ++done;
+        }
+        for (; done < phases; ++done) __syncthreads();
     }
     if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
 }
@@ -1200,55 +1384,77 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }
-    void* cells;
-    PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
-    hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells);
-    PB3D_CHECK_LAUNCH();
-    const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
     // ctx->tune_rotate_tile (PB3D_ROTATE_TILE = 64 / 128 / 256, read once in pb3d_create) pins the tile kernel: the parity tests run
     // all of them on the same grids
     const int pin = ctx->tune_rotate_tile;
     const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
     const bool packed_ok = D % 16 == 0 && W * H * D < (1ll << 32) - 64 && H >= 8;
     const bool packed = packed_ok && (pin ? pin == 256 : (W >= 512 && D >= 512 && ptiles * ((H + 15) / 16) >= (i64)ctx->cus * 4));
+    const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
+    const bool wide = !packed && (pin ? pin == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2));
+    // The step tables (cells, tile footprints, run records) depend on (matrix, offset, W, H, D) only.  A caller that repeats a step --
+    // part_carve jobs with one angle, the same process_voxel_grid on grid after grid -- finds them where the last call left them:
+    // the scratch slots are private to this path and the stream is in order.  tune misc4 = 1 switches the reuse off.
+    const int kind = packed ? 1 : (wide ? 2 : 3);
+    void *cells, *lutmap = nullptr;
+    PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
+    if (packed) PB3D_TRY(pb3d_scratch(ctx, 20, 512 * sizeof(u32), &lutmap));
+    pb3d_ctx::RotCache& rc = ctx->rot_cache;
+    const bool cached = ctx->tune_misc[4] != 1 && rc.kind == kind && rc.W == W && rc.H == H && rc.D == D && rc.cells == cells &&
+                        memcmp(rc.p, &p, sizeof(RotParams)) == 0 && rc.gen == ctx->scratch_gen;
+    rc.kind = 0;                                        // invalid until this call has queued everything
+    if (!cached) {
+        if (packed) PB3D_HIP(hipMemsetAsync(lutmap, 0, 512 * sizeof(u32), ctx->stream));
+        hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)lutmap);
+        PB3D_CHECK_LAUNCH();
+    }
+    auto remember = [&]() {
+        rc.kind = kind; rc.W = W; rc.H = H; rc.D = D; rc.cells = cells; rc.gen = ctx->scratch_gen;
+        static_assert(sizeof(rc.p) == sizeof(RotParams), "RotCache holds one RotParams");
+        memcpy(rc.p, &p, sizeof(RotParams));
+    };
     if (packed) {
         if (!ctx->packed_lds_set) {
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLdsPair));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLdsPair));
             ctx->packed_lds_set = true;
-            if (ctx->tune_misc[5] == 1) {          // development: how many workgroups of the packed kernel fit a CU
-                for (int lds = 64 * 1024; lds <= (int)kPLds; lds += 2048) {
-                    int nb = -1;
-                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rotate_bits8p<false>, PTHREADS, (size_t)lds);
-                    fprintf(stderr, "[pb3d] k_rotate_bits8p occupancy: %d workgroups/CU at %d B of LDS\n", nb, lds);
-                }
-                int nb = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rotate_bits8p<false>, PTHREADS, kPLds);
-                fprintf(stderr, "[pb3d] k_rotate_bits8p occupancy: %d workgroups/CU at %zu B of LDS (used)\n", nb, kPLds);
-            }
         }
         const int ntz = (int)((D + PT - 1) / PT);
-        void *parts, *tinfo, *recs;
+        void *parts, *tinfo, *runs;
         PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)ptiles * PPARTS * sizeof(PPart), &parts));
         PB3D_TRY(pb3d_scratch(ctx, 18, (size_t)ptiles * sizeof(PTile), &tinfo));
-        PB3D_TRY(pb3d_scratch(ctx, 19, (size_t)(W * D) * sizeof(u32), &recs));
-        hipLaunchKernelGGL(k_rot8_parts, dim3((unsigned)(ptiles * PPARTS)), dim3(PTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D, ntz, (PPart*)parts);
-        hipLaunchKernelGGL(k_rot8_tiles, dim3((unsigned)ptiles), dim3(PTHREADS), 0, ctx->stream, (const PPart*)parts, H, D, (PTile*)tinfo);
-        hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, (const CellRec*)cells, (const PTile*)tinfo, W, D,
-                           ntz, (u32*)recs);
-        PB3D_CHECK_LAUNCH();
-        int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : 32;              // planes per workgroup (multiple of 8)
-        while (TYP > 8 && ptiles * ((H + TYP - 1) / TYP) < (i64)ctx->cus * 4) TYP >>= 1;
+        PB3D_TRY(pb3d_scratch(ctx, 19, (size_t)(W * (D / 16)) * sizeof(RunRec), &runs));
+        if (!cached) {
+            hipLaunchKernelGGL(k_rot8_parts, dim3((unsigned)(ptiles * PPARTS)), dim3(PTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D, ntz, (PPart*)parts);
+            hipLaunchKernelGGL(k_rot8_tiles, dim3((unsigned)ptiles), dim3(PTHREADS), 0, ctx->stream, (const PPart*)parts, (const u32*)lutmap, H, D,
+                               (PTile*)tinfo);
+            hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, (const CellRec*)cells, (PTile*)tinfo, W, D,
+                               ntz, (RunRec*)runs);
+            PB3D_CHECK_LAUNCH();
+        }
+        const bool pair = ctx->tune_misc[3] != 1 && H >= 16;                        // misc3 = 1: the two-workgroups-per-CU form
+        int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : (pair ? 64 : 32);     // planes per workgroup (multiple of 8)
+        while (TYP > (pair ? 16 : 8) && ptiles * ((H + TYP - 1) / TYP) < (i64)ctx->cus * (pair ? 2 : 4)) TYP >>= 1;
         const int nchunks = (int)((H + TYP - 1) / TYP);
         const i64 nblk = 8 * ptiles * ((nchunks + 7) / 8);
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
-        auto kern = d_mask_src ? k_rotate_bits8p<true> : k_rotate_bits8p<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const u32*)recs,
-                           (const PTile*)tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0]);
+        // walk phase of the lanes of a row group: 1/16ths of a cell per x-row along the output direction that keeps the source row
+        // (dz/dx = -m00/m02 = cot(angle)); tune misc1 overrides (development), misc1 = -1 switches the skew off
+        int skew16 = 0;
+        if (p.m02 != 0.0) { const double ct = -p.m00 / p.m02 * 16.0; skew16 = (int)nearbyint(ct < -4096.0 ? -4096.0 : (ct > 4096.0 ? 4096.0 : ct)); }
+        if (ctx->tune_misc[1] > 0) skew16 = ctx->tune_misc[1];
+        if (ctx->tune_misc[1] < 0) skew16 = 0;
+        skew16 &= 255;                                       // only the phase modulo 16 cells matters
+        auto kern = pair ? (d_mask_src ? k_rotate_bits8p<true, true> : k_rotate_bits8p<false, true>)
+                         : (d_mask_src ? k_rotate_bits8p<true, false> : k_rotate_bits8p<false, false>);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(pair ? 2 * PTHREADS : PTHREADS), pair ? kPLdsPair : kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)runs,
+                           (const PTile*)tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0], skew16);
         PB3D_CHECK_LAUNCH();
+        remember();
         return PB3D_OK;
     }
-    const bool wide = pin ? pin == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2);
     if (wide) {
         if (!ctx->wide_lds_set) {       // > 64 KiB of LDS per workgroup has to be allowed once per device
             PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
@@ -1257,9 +1463,11 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         }
         void* trows;
         PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)xtiles * XQ * sizeof(TileRows), &trows));
-        hipLaunchKernelGGL(k_rot_tile_rows, dim3((unsigned)(xtiles * XQ)), dim3(XTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D,
-                           (int)((D + XT - 1) / XT), (TileRows*)trows);
-        PB3D_CHECK_LAUNCH();
+        if (!cached) {
+            hipLaunchKernelGGL(k_rot_tile_rows, dim3((unsigned)(xtiles * XQ)), dim3(XTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D,
+                               (int)((D + XT - 1) / XT), (TileRows*)trows);
+            PB3D_CHECK_LAUNCH();
+        }
         const int TYX = 64;
         const i64 nblkx = 8 * ((xtiles + 7) / 8) * ((H + TYX - 1) / TYX);
         PB3D_REQUIRE(nblkx < (1ll << 31), "pb3d_rotate_carve: grid too large");
@@ -1276,6 +1484,7 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
                            TYW, (int)((D + LT - 1) / LT), (int)tiles, flag, d_mask_src);
     }
     PB3D_CHECK_LAUNCH();
+    remember();
     return PB3D_OK;
 }
 
@@ -1310,13 +1519,16 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     // keep at least ~8 blocks per CU in flight for small grids
     const i64 tiles_xz = ((D + 255) / 256) * ((W + 3) / 4);
     while (TY > 1 && tiles_xz * ((H + TY - 1) / TY) < (i64)ctx->cus * 8) TY >>= 1;
-    dim3 grid((unsigned)((D + 255) / 256), (unsigned)((W + 3) / 4), (unsigned)((H + TY - 1) / TY));
-    PB3D_REQUIRE(grid.y <= 65535u * 1024u && grid.z <= 65535u, "pb3d_rotate_carve: grid too large");
+    const unsigned gx = (unsigned)((D + 255) / 256), gy = (unsigned)((W + 3) / 4), gz = (unsigned)((H + TY - 1) / TY);
+    const u64 nblk = (u64)gx * gy * gz;
+    // after a table-driven step this launch normally only reads the flag: a few workgroups per CU walk the block space if it runs
+    const u64 cap = tiled ? (u64)ctx->cus * 8 : 0x7fffffffull;
+    const unsigned launch = (unsigned)(nblk < cap ? nblk : cap);
     const bool pack = (D % 4 == 0) && (((uintptr_t)d_out & 3u) == 0);
     if (pack)
-        hipLaunchKernelGGL(k_rotate_generic<true>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src);
+        hipLaunchKernelGGL(k_rotate_generic<true>, dim3(launch), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src, gx, gy, gz);
     else
-        hipLaunchKernelGGL(k_rotate_generic<false>, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src);
+        hipLaunchKernelGGL(k_rotate_generic<false>, dim3(launch), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src, gx, gy, gz);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

@@ -137,6 +137,33 @@ __global__ __launch_bounds__(256) void k_rot_valid(RotParams p, i64 W, i64 D, in
     }
 }
 
+// Workgroup -> (z tile, x tile, plane chunk).  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels one), each with
+// its own L2.  On grids whose rows are not multiples of 128 bytes every tile row straddles two lines on both sides: the other half
+// of a written line belongs to the z-neighbour tile (or the next plane's first tile), the other half of a read line to the
+// x-neighbour.  order 0 keeps ALL tiles of one plane chunk on one XCD, z tiles adjacent in dispatch order, so both halves meet in
+// that XCD's L2 while the line is still there (partial-line writes merge, shared source lines are fetched once); order 1 is the
+// plain x-fastest linear order (neighbours land on different XCDs).
+struct TileMap { int nzt, nxt, nyc, order; };
+__device__ __forceinline__ bool tile_of_block(const TileMap m, i64* zt, i64* xt, i64* yc) {
+    const i64 b = blockIdx.x;
+    if (m.order == 1) { *zt = b % m.nzt; *xt = (b / m.nzt) % m.nxt; *yc = b / ((i64)m.nzt * m.nxt); return *yc < m.nyc; }
+    const i64 s = b >> 3;
+    *zt = s % m.nzt; *xt = (s / m.nzt) % m.nxt; *yc = (s / ((i64)m.nzt * m.nxt)) * 8 + (b & 7);
+    return *yc < m.nyc;
+}
+// planes per workgroup such that the plane chunks spread evenly over the 8 XCDs (a multiple of 8 chunks where possible) and the
+// grid still fills the chip
+static inline int planes_per_chunk(i64 H, i64 tiles, int cus, int want_ty) {
+    i64 m = (H + 8 * want_ty - 1) / (8 * want_ty);                 // chunks = 8 m
+    if (m < 1) m = 1;
+    while (tiles * 8 * m < (i64)cus * 6 && 8 * (m + 1) <= H) ++m;
+    i64 ty = (H + 8 * m - 1) / (8 * m);
+    return (int)(ty < 1 ? 1 : ty);
+}
+static inline unsigned tilemap_blocks(const TileMap& m) {
+    return m.order == 1 ? (unsigned)((i64)m.nzt * m.nxt * m.nyc) : (unsigned)(8ll * m.nzt * m.nxt * ((m.nyc + 7) / 8));
+}
+
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));     // 16-byte access at any byte alignment (rows of odd-sized grids)
 typedef u32 u32_u __attribute__((aligned(1)));
@@ -241,11 +268,13 @@ __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_
 template <int DEPTH, bool RAGGED>
 __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
-                                               i64 W, i64 H, i64 D, int TY) {
+                                               i64 W, i64 H, i64 D, int TY, TileMap tm) {
     __shared__ __attribute__((aligned(16))) u8 tiles[2][128 * 128];
     const int tid = threadIdx.x;
-    const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;     // (block order: no measurable effect, 4 orders tried)
-    const i64 y_beg = (i64)blockIdx.z * TY;
+    i64 zt, xt, yc;
+    if (!tile_of_block(tm, &zt, &xt, &yc)) return;                          // whole workgroup, before any barrier
+    const i64 x0 = xt * 128, z0 = zt * 128;
+    const i64 y_beg = yc * TY;
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
     // staging role: local source row lr = (tid >> 3) + 32 j, 16-byte block cb = tid & 7
     const int cb = tid & 7;
@@ -391,13 +420,15 @@ __device__ __forceinline__ u32x4 occ16_of(const u32x4 a, const u32x4 b, const u3
 template <bool RGBSRC, bool RAGGED>
 __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, const u8* __restrict__ occ, const u32* __restrict__ A,
                                                 const u32* __restrict__ vbits, int nw, int c0, int c2, i64 W, i64 H, i64 D, int TY,
-                                                u8* __restrict__ out) {
+                                                u8* __restrict__ out, TileMap tm) {
     __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
     __shared__ u32 asrc[128];
     __shared__ __attribute__((aligned(8))) unsigned short keepb[128 * 8 + 4];
     const int tid = threadIdx.x;
-    const i64 x0 = (i64)blockIdx.y * 128, z0 = (i64)blockIdx.x * 128;
-    const i64 y_beg = (i64)blockIdx.z * TY;
+    i64 zt, xt, yc;
+    if (!tile_of_block(tm, &zt, &xt, &yc)) return;                          // whole workgroup, before any barrier
+    const i64 x0 = xt * 128, z0 = zt * 128;
+    const i64 y_beg = yc * TY;
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
     const int cb = tid & 7;
     const i64 rbase = (i64)c0 - (z0 + 127);
@@ -620,19 +651,19 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
     if (rot90 && W <= 65535 * 128 && H <= 65535) {
         u32* bits; int nw;
         PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-        int TY = 32;
         const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
-        while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
-        dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
+        const int TY = planes_per_chunk(H, tiles, ctx->cus, 32);
+        const TileMap tm = {(int)((D + 127) / 128), (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2]};
+        dim3 grid(tilemap_blocks(tm));
 #ifndef PB3D_ROT90_DEPTH
 #define PB3D_ROT90_DEPTH 1
 #endif
         if (D % 16 == 0 && pm.c2 % 16 == 0)
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
-                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY);
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
         else
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
-                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY);
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }
@@ -710,13 +741,13 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
                        (const int*)jon, njobs, W * H, (u32*)A);
     PB3D_CHECK_LAUNCH();
     if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
-    int TY = 32;
     const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
-    while (TY > 1 && tiles * ((H + TY - 1) / TY) < (i64)ctx->cus * 6) TY >>= 1;
-    dim3 grid((unsigned)((D + 127) / 128), (unsigned)((W + 127) / 128), (unsigned)((H + TY - 1) / TY));
+    const int TY = planes_per_chunk(H, tiles, ctx->cus, 32);
+    const TileMap tm = {(int)((D + 127) / 128), (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2]};
+    dim3 grid(tilemap_blocks(tm));
     auto kern = rgbsrc ? (ragged ? k_part90<true, true> : k_part90<true, false>) : (ragged ? k_part90<false, true> : k_part90<false, false>);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw, pm.c0, pm.c2,
-                       W, H, D, TY, d_out);
+                       W, H, D, TY, d_out, tm);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

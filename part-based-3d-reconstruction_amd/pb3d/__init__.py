@@ -5,7 +5,8 @@ utils.projection_utils, utils.camera_geometry, utils.camera_estimation.compute_p
 utils.config) on top of libpb3d.so.  `install()` rebinds those names inside an imported
 reference `utils` package so notebooks 1-3 run unchanged.
 """
-from . import _hostmem, _lib, device, dist  # noqa: F401
+from . import _hostmem, _lib, device, dist, labels  # noqa: F401
+from .labels import Palette, global_carve_labels, label_to_rgb, part_carve_labels, rgb_to_label  # noqa: F401
 from ._hostmem import set_result_pool  # noqa: F401
 from .camera_estimation import CameraObjective, compute_partwise_iou, projection_iou_by_part  # noqa: F401
 from .eval_helpers_intra import compute_global_depth_buffer, project_part_visible  # noqa: F401

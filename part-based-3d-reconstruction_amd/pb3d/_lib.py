@@ -57,6 +57,7 @@ _SIGNATURES = {
     "pb3d_part_carve": [vp, u8p, i64, i64, i64, u8p, u8p, intp, intp, C.c_int, u8p],
     "pb3d_points_count_dev": [vp, vp, i64, i64, i64, C.c_int, u8p, C.c_int, C.c_int, i64p],
     "pb3d_points_fill_dev": [vp, vp, i64, i64, i64, C.c_int, u8p, C.c_int, C.c_int, i64, vp, vp],
+    "pb3d_points_extract_dev": [vp, vp, i64, i64, i64, C.c_int, u8p, C.c_int, i64, vp, vp, i64p],
     "pb3d_points_count": [vp, u8p, i64, i64, i64, C.c_int, u8p, C.c_int, C.c_int, i64p],
     "pb3d_points_fill": [vp, i64, C.POINTER(C.c_float), u8p],
     "pb3d_project_dev": [vp, vp, C.c_int, vp, i64, dblp, dblp, C.c_double, C.c_double, C.c_double, intp, C.c_int, C.c_int, vp],

@@ -151,6 +151,17 @@ def global_carve(d_bin_hw, d_rgb_hw3, h, w, angle_interval, d_out_slab, x0=0, x1
                                                  w if x1 is None else x1, _ptr(d_out_slab)))
 
 
+def rgb_to_label(d_rgb, nvox, palette_colors, d_label):
+    """synchronous (reads back the unknown-colour flag)"""
+    pal = np.ascontiguousarray(palette_colors, np.uint8)
+    _lib.check(_lib.load().pb3d_rgb_to_label_dev(_lib.ctx(), _ptr(d_rgb), int(nvox), _lib.p_u8(pal), len(pal), _ptr(d_label)))
+
+
+def label_to_rgb(d_label, nvox, palette_colors, d_rgb):
+    pal = np.ascontiguousarray(palette_colors, np.uint8)
+    _lib.check(_lib.load().pb3d_label_to_rgb_dev(_lib.ctx(), _ptr(d_label), int(nvox), _lib.p_u8(pal), len(pal), _ptr(d_rgb)))
+
+
 def synth_mask16(S, d_label_hw=None, d_binary_hw=None, d_rgb_hw3=None, d_binary_wh=None):
     _lib.check(_lib.load().pb3d_synth_mask16_dev(_lib.ctx(), S, _ptr(d_label_hw), _ptr(d_binary_hw), _ptr(d_rgb_hw3),
                                                  _ptr(d_binary_wh)))

@@ -88,6 +88,29 @@ def allgather(d_send, d_recv, bytes_per_rank):
     _lib.check(_lib.load().pb3d_allgather_dev(_lib.ctx(), _ptr(d_send), _ptr(d_recv), int(bytes_per_rank)))
 
 
+def carve_mask_sharded(d_grid_slab, W, H, D, channels, d_mask_wh, d_out_full):
+    """This rank's slab carved into its slot of d_out_full + ONE in-place all-gather (pb3d_carve_mask_sharded_dev); enqueue only."""
+    from .device import _ptr
+    _lib.check(_lib.load().pb3d_carve_mask_sharded_dev(_lib.ctx(), _ptr(d_grid_slab), int(W), int(H), int(D), int(channels), _ptr(d_mask_wh),
+                                                       _ptr(d_out_full)))
+
+
+def global_carve_sharded(d_bin_hw, d_rgb_hw3, h, w, angle_interval, d_out_full):
+    from .device import _ptr
+    _lib.check(_lib.load().pb3d_global_carve_sharded_dev(_lib.ctx(), _ptr(d_bin_hw), _ptr(d_rgb_hw3), int(h), int(w), int(angle_interval),
+                                                         _ptr(d_out_full)))
+
+
+def carve_labels_sharded(d_label_slab, W, H, D, d_mask_wh, d_label_full, palette_colors=None, d_rgb_full=None):
+    """The compact form of the reassembly: the slab is carved as LABELS (1 B/voxel), ONE all-gather moves a
+    third of the bytes of the RGB form, and -- only if d_rgb_full is given -- the reassembled label volume is expanded to RGB
+    locally.  palette_colors: (n,3) uint8 (label k <-> palette_colors[k-1])."""
+    from .device import _ptr
+    pal = np.zeros((0, 3), np.uint8) if palette_colors is None else np.ascontiguousarray(palette_colors, np.uint8)
+    _lib.check(_lib.load().pb3d_carve_labels_sharded_dev(_lib.ctx(), _ptr(d_label_slab), int(W), int(H), int(D), _ptr(d_mask_wh), _ptr(d_label_full),
+                                                         _lib.p_u8(pal), len(pal), _ptr(d_rgb_full)))
+
+
 def comm_destroy():
     _lib.check(_lib.load().pb3d_comm_destroy(_lib.ctx()))
 

@@ -4,7 +4,14 @@ Mirrors reference utils/mask_utils.py: load_mask (:14-33), load_and_prepare_mask
 mask_parts_from_image (:89-97).  Upstream decodes and resizes with OpenCV, which this build does not depend on:
 PNGs are decoded with Pillow and resized with OpenCV's INTER_NEAREST rule
     src = min(floor(dst * src_n / dst_n), src_n - 1),   dsize = (int(w*s), int(h*s)),  s = max_dim / max(h, w)
-(with this rule the pipeline reproduces the reference's stored Taj grid position-exactly)."""
+(with this rule the pipeline reproduces the reference's stored Taj grid position-exactly).
+
+Parity note (unpinned): upstream calls cv2.resize(img, dsize, cv2.INTER_NEAREST) (mask_utils.py:60) -- the third POSITIONAL slot of
+cv2.resize is `dst`, not `interpolation`; a cv2 build that accepts the integer there resizes with its default INTER_LINEAR.  cv2 is
+not available in this image, so which one upstream's environment ran cannot be observed; the stored results/1 artefacts are consistent
+with nearest, which is what this module implements (`interpolation="nearest"`).  `interpolation="linear"` is offered for callers who
+know their cv2 took the default: OpenCV's half-pixel bilinear rule in fixed point is NOT reproduced bit for bit -- it is a plain
+float bilinear resize and is outside every parity claim."""
 import os
 
 import numpy as np
@@ -19,15 +26,24 @@ def _read_rgb(path):
     return np.array(Image.open(path).convert("RGB"))
 
 
-def resize_to_max(img, max_dim):
-    """nearest-neighbour resize so that the longer side becomes max_dim (reference :57-60)"""
+def resize_to_max(img, max_dim, interpolation="nearest"):
+    """resize so that the longer side becomes max_dim (reference :57-60); see the module docstring for `interpolation`"""
     h, w = img.shape[:2]
+    if interpolation == "linear":
+        from PIL import Image
+        s = max_dim / max(h, w)
+        return np.array(Image.fromarray(np.asarray(img)).resize((int(w * s), int(h * s)), Image.BILINEAR))
+    if interpolation != "nearest":
+        raise ValueError("interpolation is 'nearest' or 'linear'")
     s = max_dim / max(h, w)
     nw, nh = int(w * s), int(h * s)
     if nw <= 0 or nh <= 0:
         raise ValueError("resize to an empty image")
-    xs = np.minimum(np.floor(np.arange(nw) * (w / nw)).astype(np.int64), w - 1)
-    ys = np.minimum(np.floor(np.arange(nh) * (h / nh)).astype(np.int64), h - 1)
+    # OpenCV's INTER_NEAREST index rule, with its own arithmetic (imgproc/resize.cpp): inv_scale = (double)dst / src;
+    # ifx = 1.0 / inv_scale; sx = min(cvFloor(x * ifx), src - 1).  (x * (src / dst) differs from it by an ulp for some size pairs.)
+    ifx = 1.0 / (nw / float(w)); ify = 1.0 / (nh / float(h))
+    xs = np.minimum(np.floor(np.arange(nw) * ifx).astype(np.int64), w - 1)
+    ys = np.minimum(np.floor(np.arange(nh) * ify).astype(np.int64), h - 1)
     return np.ascontiguousarray(img[ys][:, xs])
 
 

@@ -52,16 +52,27 @@ def _occupancy(grid):
 
 def carve_voxel_grid_with_masks(voxel_grid, combined_mask):
     """np.where(mask[x,y], grid, 0) broadcast over z (and channel); reference :76-97."""
-    g = _lib.as_u8(voxel_grid, "voxel_grid")
-    if g.ndim not in (3, 4) or (g.ndim == 4 and g.shape[3] != 3):
-        raise ValueError(f"voxel_grid must be (W,H,D) or (W,H,D,3), got {g.shape}")
+    g = np.ascontiguousarray(np.asarray(voxel_grid))
+    if g.ndim not in (3, 4):
+        raise ValueError(f"voxel_grid must be (W,H,D) or (W,H,D,C), got {g.shape}")
     W, H, D = g.shape[:3]
     mask = _mask_to_wh(combined_mask, W, H)
     if mask.ndim == 2:
         m = _lib.truth_u8(mask)
-        out = _hostmem.empty_like(g)
-        _lib.check(_lib.load().pb3d_carve_mask(_lib.ctx(), _lib.p_u8(g), W, H, D, 3 if g.ndim == 4 else 1,
-                                               _lib.p_u8(m), _lib.p_u8(out)))
+        if g.dtype == np.uint8 and (g.ndim == 3 or g.shape[3] == 3):
+            out = _hostmem.empty_like(g)
+            _lib.check(_lib.load().pb3d_carve_mask(_lib.ctx(), _lib.p_u8(g), W, H, D, 3 if g.ndim == 4 else 1,
+                                                   _lib.p_u8(m), _lib.p_u8(out)))
+            return out
+        # Any other numeric dtype / channel count: np.where(mask, grid, 0) keeps the grid's dtype and either copies an element
+        # bit for bit or writes a zero, so the op is "zero the bytes of the dropped (x,y) columns" whatever the elements are.
+        if g.dtype.kind not in "uifc" or np.result_type(g.dtype, 0) != g.dtype:
+            raise TypeError(f"voxel_grid dtype {g.dtype} is not supported (np.where would change it); use a numeric dtype")
+        col_bytes = int(np.prod(g.shape[2:], dtype=np.int64)) * g.dtype.itemsize
+        out = _hostmem.empty(g.shape, g.dtype)
+        if g.size:
+            _lib.check(_lib.load().pb3d_carve_mask(_lib.ctx(), g.view(np.uint8).ctypes.data_as(_lib.u8p), W, H, col_bytes, 1, _lib.p_u8(m),
+                                                   out.view(np.uint8).ctypes.data_as(_lib.u8p)))
         return out
     if mask.ndim == 3 and mask.shape[2] == 3:
         # Upstream's RGB-mask branch (:90-95) selects with a (W,H,1,1) array against a (W,H,D)

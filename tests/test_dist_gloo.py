@@ -92,13 +92,24 @@ def _worker(rank, world, port, q):
         g24 = orc.global_carve(bin24, rgb24, 90)                                    # (32, 24, 32, 3)
         ok_f = ok_f and np.array_equal(gathered(orc.part_carve(y_slab_grid(g24, rank, world), y_slab_image(rgb24, rank, world), jobs)),
                                        orc.part_carve(g24, rgb24, jobs))
+        # (g) compact reassembly: the slab is carved as 1-byte LABELS, ONE all_gather moves a third of the bytes, every
+        #     rank expands the reassembled label volume locally: == the RGB gather of (a), byte for byte
+        pal16 = synth_host.palette16()                                         # the 16 colours of the synthetic grid; label k <-> pal16[k-1]
+        table = np.concatenate([np.zeros((1, 3), np.uint8), pal16])
+        key = lambda a: a[..., 0].astype(np.int64) | (a[..., 1].astype(np.int64) << 8) | (a[..., 2].astype(np.int64) << 16)
+        lut = {int(key(table[k])): k for k in range(len(table))}
+        slab_lab = np.vectorize(lut.__getitem__, otypes=[np.uint8])(key(slab_in))
+        lab_out = orc.carve_voxel_grid_with_masks(slab_lab, m_wh[x0:x1])        # the same carve op, C = 1
+        parts = [torch.empty_like(torch.from_numpy(lab_out)) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(lab_out))
+        ok_g = np.array_equal(table[np.concatenate([p.numpy() for p in parts], axis=0)], full)
         # (d) max-over-ranks timing reduction used by bench.py
         t = torch.tensor([0.25 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ok_d = float(t) == 0.25 + world - 1
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, ok_a, ok_b, ok_c, ok_d and ok_e and ok_f))
+        q.put((rank, ok_a, ok_b, ok_c, ok_d and ok_e and ok_f and ok_g))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "error", traceback.format_exc(), str(e), None))

@@ -173,6 +173,15 @@ def test_carve_vs_oracle_shapes(pb3d_gpu, oracle):
             for frac in (0.0, 0.5, 1.0):
                 m = rng.random((H, W)) < frac
                 assert np.array_equal(pb3d_gpu.carve_voxel_grid_with_masks(grid, m), oracle.carve_voxel_grid_with_masks(grid, m)), (W, H, D, nd, frac)
+    # other dtypes / channel counts (upstream's np.where keeps the grid's dtype; SURVEY 8(b): the signature takes any array)
+    for dt, tail in ((np.float32, ()), (np.int16, (3,)), (np.float64, (2,)), (np.uint8, (4,)), (np.int64, ()), (np.uint16, (3,))):
+        grid = (rng.normal(size=(9, 7, 13) + tail) * 100).astype(dt)
+        m = rng.random((7, 9)) < 0.5
+        got = pb3d_gpu.carve_voxel_grid_with_masks(grid, m)
+        want = np.where(m.T[:, :, None] if not tail else m.T[:, :, None, None], grid, 0)
+        assert got.dtype == want.dtype == np.dtype(dt) and np.array_equal(got, want), dt
+    with pytest.raises(TypeError):
+        pb3d_gpu.carve_voxel_grid_with_masks(np.ones((3, 3, 3), bool), np.ones((3, 3), bool))
     # empty grids
     for shp in [(0, 4, 4), (4, 0, 4), (4, 4, 0)]:
         e = np.zeros(shp, np.uint8)
@@ -887,3 +896,235 @@ def test_deform_tuples_batched_equals_one_at_a_time(pb3d_gpu):
                 assert ious[k] == 0.0 and len(pb3d_gpu.deform_part(grid, PC, part, deforms[k], image.shape[:2])[0]) == 0
             else:
                 assert ious[k] == pb3d_gpu.evaluate_part_deform(grid, PC, part, deforms[k], image, cam)[1], (part, deforms[k])
+
+
+@pytest.mark.gpu
+def test_label_form_expands_to_the_rgb_results(pb3d_gpu, oracle, golden):
+    """row N3, device half: palette -> 1-byte labels, the carve ops on label volumes, and the expansion back: every result
+    equals, byte for byte, what the RGB entry points (and the oracle) return."""
+    PC = pb3d_gpu.PART_COLORS
+    pal = pb3d_gpu.Palette.from_part_colors(PC)
+    rng = np.random.default_rng(91)
+    # conversions: every palette colour + black, ragged sizes, round trip; unknown colours / labels are refused
+    for shape in ((5, 7, 9), (16, 3, 32), (1, 1, 1), (33, 2, 17)):
+        lab = rng.integers(0, len(pal) + 1, shape).astype(np.uint8)
+        rgb = pal.table()[lab]
+        assert np.array_equal(pb3d_gpu.rgb_to_label(rgb, pal), lab)
+        assert np.array_equal(pb3d_gpu.label_to_rgb(lab, pal), rgb)
+    bad = pal.table()[rng.integers(0, len(pal) + 1, (4, 4, 4))].copy(); bad[1, 2, 3] = (1, 2, 3)
+    with pytest.raises(ValueError, match="neither black nor in the palette"):
+        pb3d_gpu.rgb_to_label(bad, pal)
+    with pytest.raises(ValueError, match="exceeds the palette"):
+        pb3d_gpu.label_to_rgb(np.full((3, 3), len(pal) + 1, np.uint8), pal)
+    with pytest.raises(ValueError):
+        pb3d_gpu.Palette([(1, 2, 3), (1, 2, 3)])
+    # the real masks: global_carve and part_carve in label form == the RGB path == the oracle
+    for name in ("f4_Akbar_64", "f4_Taj_96"):
+        g = golden(name)
+        sem, binary = g["ext"] if "ext" in g.files else g["sem"], g["binary"]
+        lab_mask = pal.mask_to_labels(sem)
+        assert lab_mask.shape == sem.shape[:2] and np.array_equal(pal.table()[lab_mask], sem)
+        for ai in (90, 45):
+            want = oracle.global_carve(binary, sem, ai)
+            lg = pb3d_gpu.global_carve_labels(binary, lab_mask, ai)
+            assert lg.dtype == np.uint8 and lg.shape == want.shape[:3]
+            assert np.array_equal(pb3d_gpu.label_to_rgb(lg, pal), want), (name, ai)
+        gc = oracle.global_carve(binary, sem, 90)
+        lgc = pb3d_gpu.rgb_to_label(gc, pal)
+        # carve_voxel_grid_with_masks takes the label volume as it is (C = 1)
+        m2 = rng.random(binary.shape) < 0.7
+        assert np.array_equal(pb3d_gpu.label_to_rgb(pb3d_gpu.carve_voxel_grid_with_masks(lgc, m2), pal), oracle.carve_voxel_grid_with_masks(gc, m2))
+        present = [n for n in PC if np.all(sem == np.array(PC[n], np.uint8), axis=-1).any()]
+        jobs = [([present[0]], 90), (present[1:3], 45), ([present[-1]], 90)]
+        want = oracle.part_carve(gc, sem, jobs)
+        assert np.array_equal(pb3d_gpu.part_carve(gc, sem, jobs), want)
+        assert np.array_equal(pb3d_gpu.label_to_rgb(pb3d_gpu.part_carve_labels(lgc, lab_mask, jobs, pal), pal), want), name
+
+
+@pytest.mark.gpu
+def test_sharded_entry_points_single_rank_rccl(pb3d_gpu, oracle):
+    """pb3d_carve_mask_sharded_dev / pb3d_global_carve_sharded_dev / pb3d_carve_labels_sharded_dev through RCCL on a 1-rank
+    communicator (slab = the whole grid): the RGB gather, the label gather and its local expansion all equal the unsharded op;
+    pb3d_comm_info reports what RCCL itself sees."""
+    from pb3d import device as dev, dist
+    import synth_host
+    S = 64
+    lab, binary, rgb = synth_host.mask16(S)
+    pal16 = dev.synth_palette16()
+    sem = synth_host.sem_slab(0, S, S, S, seed=4)
+    m_wh = np.ascontiguousarray(binary.T)
+    want = oracle.carve_voxel_grid_with_masks(sem, binary)          # square grid: the (H,W) reading of the mask wins
+    d_in = dev.from_numpy(sem); d_m = dev.from_numpy(m_wh); d_full = dev.DeviceBuffer(sem.nbytes)
+    d_lab_in = dev.DeviceBuffer(S ** 3); d_lab_full = dev.DeviceBuffer(S ** 3); d_rgb2 = dev.DeviceBuffer(sem.nbytes)
+    d_b = dev.from_numpy(binary); d_rgbm = dev.from_numpy(rgb); d_gc = dev.DeviceBuffer(sem.nbytes)
+    with pytest.raises(ValueError, match="pb3d_comm_init first"):
+        dist.carve_mask_sharded(d_in, S, S, S, 3, d_m, d_full)
+    dist.comm_init(dist.new_unique_id(), 0, 1)
+    try:
+        assert dist.comm_info() == (0, 1)
+        dist.carve_mask_sharded(d_in, S, S, S, 3, d_m, d_full)
+        dev.rgb_to_label(d_in, S ** 3, pal16, d_lab_in)
+        dist.carve_labels_sharded(d_lab_in, S, S, S, d_m, d_lab_full, pal16, d_rgb2)
+        dist.global_carve_sharded(d_b, d_rgbm, S, S, 90, d_gc)
+        dev.sync()
+        assert np.array_equal(d_full.download(sem.shape), want)
+        assert np.array_equal(d_rgb2.download(sem.shape), want)                                   # label gather + local expansion == RGB gather
+        labs = d_lab_full.download((S, S, S))
+        assert labs.max() <= 16 and np.array_equal(np.concatenate([np.zeros((1, 3), np.uint8), pal16])[labs], want)
+        assert np.array_equal(d_gc.download(sem.shape), oracle.global_carve(binary, rgb, 90))
+    finally:
+        dist.comm_destroy()
+        for b in (d_in, d_m, d_full, d_lab_in, d_lab_full, d_rgb2, d_b, d_rgbm, d_gc):
+            b.free()
+
+
+def _structured_color_grid(pb3d_gpu, S):
+    """global_carve(binary, rgb, 90) of the synthetic 16-label mask, resident in HBM: the realistic 1024^3 colour grid of opbench."""
+    from pb3d import device as dev
+    d_bhw = dev.DeviceBuffer(S * S); d_rgb = dev.DeviceBuffer(S * S * 3)
+    dev.synth_mask16(S, d_binary_hw=d_bhw, d_rgb_hw3=d_rgb)
+    d_col = dev.DeviceBuffer(S ** 3 * 3)
+    dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col)
+    dev.sync()
+    d_bhw.free(); d_rgb.free()
+    return d_col
+
+
+@pytest.mark.gpu
+def test_full_size_points_and_projection_1024(pb3d_gpu, oracle):
+    """M7 / M8 at the size opbench times them (1024^3 grid -> ~416 M points = 5 GB of float32, past the 2^32-byte mark):
+    * the point count equals an INDEPENDENT device reduction (per-colour voxel counts from the IoU kernel);
+    * whole X-planes of the point list -- first, middle, the one holding byte 2^32 of the buffer, last -- equal np.where on the
+      matching plane of the grid (coordinates, colours, order);
+    * the projection of all points equals the max-merge of 8 index-keyed shards, and on every pixel hit by one of the last two
+      million points it equals the oracle's projection of those points alone (the highest index wins a pixel)."""
+    import ctypes as C
+    from pb3d import device as dev
+    L, lib = pb3d_gpu._lib, pb3d_gpu._lib.load()
+    S = int(os.environ.get("PB3D_TEST_FULL_SIZE", "1024"))
+    nvox = S ** 3
+    PC = pb3d_gpu.PART_COLORS
+    cols = np.ascontiguousarray(np.array(list(PC.values()), np.uint8))
+    d_col = _structured_color_grid(pb3d_gpu, S)
+
+    def count(planes):
+        n = C.c_int64(0)
+        L.check(lib.pb3d_points_count_dev(L.ctx(), C.c_void_p(d_col.ptr), planes, S, S, 3, L.p_u8(cols), len(cols), 1, C.byref(n)))
+        return n.value
+    npts = count(S)
+    inter = np.zeros(len(cols), np.int64); uni = np.zeros(len(cols), np.int64)
+    L.check(lib.pb3d_partwise_iou_dev(L.ctx(), C.c_void_p(d_col.ptr), C.c_void_p(d_col.ptr), nvox, L.p_u8(cols), len(cols),
+                                      inter.ctypes.data_as(L.i64p), uni.ctypes.data_as(L.i64p)))
+    assert npts == int(inter.sum()) == int(uni.sum()) and npts > 0
+    if S == 1024:
+        assert npts * 12 > 2 ** 32                                           # the buffer really crosses the 4 GiB mark
+    d_pts = dev.DeviceBuffer(npts * 12); d_pc = dev.DeviceBuffer(npts * 3)
+    L.check(lib.pb3d_points_fill_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), 1, npts, C.c_void_p(d_pts.ptr),
+                                     C.c_void_p(d_pc.ptr)))
+    dev.sync()
+    key = lambda a: a[..., 0].astype(np.uint32) | (a[..., 1].astype(np.uint32) << 8) | (a[..., 2].astype(np.uint32) << 16)
+    ckeys = key(cols)
+    # plane that holds point index 2^32 / 12 (bisection on the prefix counts), plus first / middle / last non-empty planes
+    target = min(npts - 1, (2 ** 32) // 12)
+    lo, hi = 0, S
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if count(mid) <= target: lo = mid
+        else: hi = mid
+    planes = sorted({lo, S // 2, S - 1} | {next(a for a in range(S) if count(a + 1) > 0)} | {max(a for a in range(S) if count(a + 1) > count(a))})
+    for a in planes:
+        c0, c1 = count(a), count(a + 1)
+        plane = d_col.download((S, S, 3), byte_offset=a * S * S * 3)
+        sel = np.isin(key(plane), ckeys)
+        a1, a2 = np.nonzero(sel)
+        assert c1 - c0 == len(a1), a
+        if c1 == c0:
+            continue
+        got_p = d_pts.download((c1 - c0, 3), np.float32, byte_offset=c0 * 12)
+        got_c = d_pc.download((c1 - c0, 3), byte_offset=c0 * 3)
+        want_p = np.stack([a2, a1, np.full(len(a1), a)], axis=1).astype(np.float32)
+        assert np.array_equal(got_p, want_p) and np.array_equal(got_c, plane[a1, a2]), a
+    # ---- the one-pass form (decoupled look-back): same count, same rows, in the same order; too small a capacity is reported
+    d_pts2 = dev.DeviceBuffer(npts * 12); d_pc2 = dev.DeviceBuffer(npts * 3)
+    n2 = C.c_int64(0)
+    L.check(lib.pb3d_points_extract_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), npts, C.c_void_p(d_pts2.ptr),
+                                        C.c_void_p(d_pc2.ptr), C.byref(n2)))
+    assert n2.value == npts
+    for a in planes:
+        c0, c1 = count(a), count(a + 1)
+        if c1 > c0:
+            assert np.array_equal(d_pts2.download((c1 - c0, 3), np.float32, byte_offset=c0 * 12), d_pts.download((c1 - c0, 3), np.float32, byte_offset=c0 * 12))
+            assert np.array_equal(d_pc2.download((c1 - c0, 3), byte_offset=c0 * 3), d_pc.download((c1 - c0, 3), byte_offset=c0 * 3))
+    L.check(lib.pb3d_points_extract_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), npts // 2, C.c_void_p(d_pts2.ptr),
+                                        C.c_void_p(d_pc2.ptr), C.byref(n2)))
+    assert n2.value == npts                                                  # the count is still exact; the caller sees n > capacity
+    d_pts2.free(); d_pc2.free()
+    # ---- M8 on the full list
+    from pb3d.camera_geometry import look_at_rotation
+    cam = np.array([S / 2, S / 2, -2.5 * S], np.float32); tgt = np.array([S / 2, S / 2, S / 2], np.float32)
+    R = np.ascontiguousarray(look_at_rotation(cam, tgt), np.float64); cd = np.ascontiguousarray(cam, np.float64)
+    f, cx, cy = float(1.2 * S), S / 2.0, S / 2.0
+    prec = (C.c_int * 4)(0, 0, 0, 0)
+    d_img = dev.DeviceBuffer(S * S * 3)
+    L.check(lib.pb3d_project_dev(L.ctx(), C.c_void_p(d_pts.ptr), 0, C.c_void_p(d_pc.ptr), npts, L.p_dbl(R), L.p_dbl(cd), f, cx, cy, prec, S, S,
+                                 C.c_void_p(d_img.ptr)))
+    img = d_img.download((S, S, 3))
+    d_keys = dev.DeviceBuffer(S * S * 8)
+    merged = np.zeros((S, S), np.uint64)
+    for r in range(8):
+        i0, i1 = pb3d_gpu.dist.point_shard_bounds(npts, r, 8)
+        L.check(lib.pb3d_project_keys_dev(L.ctx(), C.c_void_p(d_pts.ptr + i0 * 12), 0, C.c_void_p(d_pc.ptr + i0 * 3), i1 - i0, i0, L.p_dbl(R), L.p_dbl(cd),
+                                          f, cx, cy, prec, S, S, C.c_void_p(d_keys.ptr)))
+        merged = np.maximum(merged, d_keys.download((S, S), np.uint64))
+    assert np.array_equal(pb3d_gpu.dist.resolve_keys(merged), img)
+    ntail = min(npts, 2_000_000)
+    tail_p = d_pts.download((ntail, 3), np.float32, byte_offset=(npts - ntail) * 12)
+    tail_c = d_pc.download((ntail, 3), byte_offset=(npts - ntail) * 3)
+    sub = oracle.project_colored_voxels(tail_p, tail_c, cam, tgt, f, cx, cy, S, S)
+    hit = np.zeros((S, S), bool)
+    one = oracle.project_colored_voxels(tail_p, np.full((ntail, 3), 255, np.uint8), cam, tgt, f, cx, cy, S, S)
+    hit = one.any(-1)
+    assert hit.any() and np.array_equal(img[hit], sub[hit])
+    for b in (d_col, d_pts, d_pc, d_img, d_keys):
+        b.free()
+
+
+@pytest.mark.gpu
+def test_full_size_connected_components_1024(pb3d_gpu, oracle):
+    """CCL at the size opbench times it: the int32 label volume of one part colour of the 1024^3 structured grid (4 GiB) equals
+    the oracle's scipy-numbered labelling voxel for voxel, and the per-component statistics equal bincounts of it."""
+    import ctypes as C
+    from pb3d import device as dev
+    L, lib = pb3d_gpu._lib, pb3d_gpu._lib.load()
+    S = int(os.environ.get("PB3D_TEST_FULL_SIZE", "1024"))
+    nvox = S ** 3
+    d_col = _structured_color_grid(pb3d_gpu, S)
+    col = np.array(pb3d_gpu.PART_COLORS["full_building"], np.uint8)
+    d_lab = dev.DeviceBuffer(nvox * 4)
+    ncomp = C.c_int64(0)
+    L.check(lib.pb3d_label_color_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, L.p_u8(col), C.c_void_p(d_lab.ptr), C.byref(ncomp)))
+    n = ncomp.value
+    bbox = (C.c_int64 * (6 * max(n, 1)))(); cnt = (C.c_int64 * max(n, 1))(); csum = (C.c_int64 * (3 * max(n, 1)))()
+    L.check(lib.pb3d_component_stats_dev(L.ctx(), C.c_void_p(d_lab.ptr), S, S, S, n, bbox, cnt, csum))
+    # the oracle labels the same mask plane block by plane block is not possible (components cross planes): whole volume at once
+    mask = np.empty((S, S, S), np.uint8)
+    step = max(1, S // 8)
+    for x0 in range(0, S, step):
+        g = d_col.download((step, S, S, 3), byte_offset=x0 * S * S * 3)
+        mask[x0:x0 + step] = np.all(g == col, axis=-1)
+    d_col.free()
+    want, nw = oracle.label6(mask)
+    assert n == nw and n > 0
+    for x0 in range(0, S, step):                                             # 4 GiB of labels, compared in slabs
+        got = d_lab.download((step, S, S), np.int32, byte_offset=x0 * S * S * 4)
+        assert np.array_equal(got, want[x0:x0 + step]), x0
+    d_lab.free()
+    counts = np.bincount(want.ravel(), minlength=n + 1)[1:]
+    assert np.array_equal(np.array(cnt[:n]), counts)
+    xs = np.arange(S, dtype=np.int64)
+    for axis in range(3):                                                    # coordinate sums per component along each axis
+        sums = np.zeros(n + 1, np.int64)
+        moved = np.moveaxis(want, axis, 0)
+        for v in range(S):
+            sums += np.bincount(moved[v].ravel(), minlength=n + 1) * v
+        assert np.array_equal(np.array(csum[:3 * n]).reshape(n, 3)[:, axis], sums[1:]), axis

@@ -106,7 +106,11 @@ def main():
         fn = lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr),
                                                       ang, skip, 6, C.c_void_p(d_out.ptr)))
         ms = timeit(fn, max(2, a.reps // 2), warm=1)
-        report("M6", "part_carve, six 90-degree jobs", ms, 36, {"jobs": 6, "ms_per_job": round(ms / 6, 4)})
+        # the six jobs run as ONE fused sweep (k_part90): it owes a read of the colour grid as occupancy source (3 B), a read of
+        # the kept rows as output source (<= 3 B) and the write (3 B) -- <= 9 B/voxel whatever the number of jobs.  (SURVEY's
+        # 6 B/voxel PER JOB prices the reference's job-by-job execution, which this sweep does not perform.)
+        report("M6", "part_carve, six 90-degree jobs (one fused sweep)", ms, 9, {"jobs": 6, "ms_per_job": round(ms / 6, 4),
+                                                                                 "reference_execution_B_per_voxel": 36})
         for b in (d_ms, d_mc, d_out):
             b.free()
     if "A9" in ops:
@@ -138,6 +142,13 @@ def main():
         fillfrac = npts / nvox
         if "M7" in ops:
             report("M7", "get_voxel_points_by_parts (10 parts): count + fill", ms, round(3 + 15 * fillfrac, 3), {"points": npts, "fill": round(fillfrac, 4)})
+            n1 = C.c_int64(0)
+            one = lambda: L.check(lib.pb3d_points_extract_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), npts,
+                                                              C.c_void_p(d_pts.ptr), C.c_void_p(d_pc.ptr), C.byref(n1)))
+            ms1 = timeit(one, max(2, a.reps // 2), warm=1)
+            assert n1.value == npts
+            report("M7", "get_voxel_points_by_parts (10 parts): ONE pass (pb3d_points_extract_dev, decoupled look-back)", ms1,
+                   round(3 + 15 * fillfrac, 3), {"points": npts, "fill": round(fillfrac, 4)})
         if "M8" in ops and npts:
             from pb3d.camera_geometry import look_at_rotation
             cam = np.array([S / 2, S / 2, -2.5 * S], np.float32); tgt = np.array([S / 2, S / 2, S / 2], np.float32)
@@ -148,8 +159,10 @@ def main():
             fn = lambda: L.check(lib.pb3d_project_dev(L.ctx(), C.c_void_p(d_pts.ptr), 0, C.c_void_p(d_pc.ptr), npts, L.p_dbl(R), L.p_dbl(cd),
                                                       float(1.2 * S), S / 2.0, S / 2.0, prec, Hi, Wi, C.c_void_p(d_img.ptr)))
             ms = timeit(fn, max(2, a.reps // 2), warm=1)
+            # 12 B of coordinates per point are read by the point kernel; colours are only read for the <= H*W winners
             r = {"op": "M8", "name": "project_colored_voxels (f32 camera)", "size": S, "ms": round(ms, 4), "points": npts,
-                 "Mpts_s": round(npts / ms / 1e3, 1), "alg_B_per_point": 15, "alg_GB_s": round(15 * npts / ms / 1e6, 1)}
+                 "Mpts_s": round(npts / ms / 1e3, 1), "alg_B_per_point": 12, "alg_GB_s": round(12 * npts / ms / 1e6, 1),
+                 "frac_of_8TBs": round(12 * npts / ms / 1e6 / PEAK, 4)}
             print(json.dumps(r), flush=True)
             d_img.free()
         d_pts.free(); d_pc.free()

@@ -19,8 +19,16 @@ def timeit(fn, reps=5):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="128x123x128,512x278x512,355x512x355,512x512x512,437x512x437,500x400x500")
+    ap.add_argument("--tune", default="", help="development knobs, e.g. misc2=1,rotate_tile=128 (pb3d_set_tuning)")
+    a = ap.parse_args()
+    tune = dict(kv.split("=") for kv in a.tune.split(",") if kv)
+    for k, v in tune.items():
+        pb3d._lib.set_tuning(k, int(v))
     rng = np.random.default_rng(5)
-    shapes = [(128, 123, 128), (512, 278, 512), (355, 512, 355), (512, 512, 512), (437, 512, 437), (500, 400, 500)]
+    shapes = [tuple(int(v) for v in sh.split("x")) for sh in a.shapes.split(",")]
     for (W, H, D) in shapes:
         nvox = W * H * D
         m_hw = (rng.random((H, W)) < 0.8)
@@ -58,7 +66,7 @@ def main():
         rows.update(rows0)
         for name, (ms, bpv) in rows.items():
             print(json.dumps({"shape": [W, H, D], "op": name, "ms": round(ms, 4), "Mvoxel_s": round(nvox / ms / 1e3, 1),
-                              "alg_GB_s": round(bpv * nvox / ms / 1e6, 1)}), flush=True)
+                              "alg_GB_s": round(bpv * nvox / ms / 1e6, 1), **({"tune": tune} if tune else {})}), flush=True)
         for b in (d_mwh, d_bhw, d_rgb, d_occ, d_o, d_t, d_col):
             b.free()
 
