@@ -144,15 +144,17 @@ int pb3d_points_count(pb3d_ctx* ctx, const uint8_t* grid, int64_t A0, int64_t A1
     // look-back, csrc/points.hip) and pb3d_points_fill only downloads them -- the grid is read once instead of twice.
     const i64 nvox = A0 * A1 * A2;
     ctx->pts.extracted = false;
-    if (stride == 1 && nvox > 0 && (C == 3 || ncolors == 0) && (size_t)nvox * (12 + (size_t)C) <= ((size_t)8 << 30)) {
+    // (measured on MI355X the look-back costs more than the second read of the grid saves -- 4.1 ms against 2.4 ms at 1024^3, flag round
+    //  trips between XCDs are microseconds -- so the two-pass protocol stays the default; tune misc2 = 3 selects the one-pass form)
+    if (ctx->tune_misc[2] == 3 && stride == 1 && nvox > 0 && (C == 3 || ncolors == 0) && (size_t)nvox * (12 + (size_t)C) <= ((size_t)8 << 30)) {
         void *dp, *dc;
         PB3D_TRY(pb3d_scratch(ctx, 1, (size_t)nvox * 3 * sizeof(float), &dp));
         PB3D_TRY(pb3d_scratch(ctx, 3, (size_t)nvox * C, &dc));
-        PB3D_TRY(pb3d_points_extract_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, nvox, (float*)dp, (u8*)dc, n));
-        ctx->pts.extracted = true;
-    } else {
-        PB3D_TRY(pb3d_points_count_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, stride, n));
+        const int rc = pb3d_points_extract_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, nvox, (float*)dp, (u8*)dc, n);
+        if (rc == PB3D_OK) ctx->pts.extracted = true;
+        else if (rc != PB3D_EUNSUPPORTED) return rc;
     }
+    if (!ctx->pts.extracted) PB3D_TRY(pb3d_points_count_dev(ctx, (const u8*)dg, A0, A1, A2, C, colors, ncolors, stride, n));
     ctx->pts.A0 = A0; ctx->pts.A1 = A1; ctx->pts.A2 = A2; ctx->pts.C = C;
     ctx->pts.ncolors = ncolors; ctx->pts.stride = stride; ctx->pts.n = *n;
     if (ncolors) memcpy(ctx->pts.colors, colors, (size_t)3 * ncolors);

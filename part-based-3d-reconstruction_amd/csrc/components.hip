@@ -52,7 +52,7 @@ __device__ __forceinline__ bool is_color(const u8* __restrict__ g, i64 v, u8 r, 
 
 // parent[v] = first voxel of v's run of members along the fastest axis, cut at row starts and at the 64-voxel segments a
 // wavefront covers (ballot arithmetic, no atomics): the a2-links inside a segment are never made one by one.
-__global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 n, i64 A2, u8 r, u8 g, u8 b, int* __restrict__ parent,
+__global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 n, pb3d_magic m2, u8 r, u8 g, u8 b, int* __restrict__ parent,
                                                   u8* __restrict__ member) {
     const int lane = threadIdx.x & 63;
     const i64 stride = (i64)gridDim.x * blockDim.x;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
         const bool m = v < n && is_color(grid, v, r, g, b);
         const u64 bal = __ballot(m);
         const bool prev = lane > 0 && ((bal >> (lane - 1)) & 1ull);
-        const bool start = m && (!prev || v % A2 == 0);
+        const bool start = m && (!prev || (u32)v - pb3d_div((u32)v, m2) * m2.d == 0u);       // v % A2 == 0 (n < 2^31)
         const u64 starts = __ballot(start);
         if (v < n) {
             int par = (int)v;
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
 // Links across the three axes.  A link (v, v+s) is skipped when the pair one step back along the fastest axis, (v-1, v-1+s),
 // exists in the same row: it connects the same two runs (runs are already linked inside by k_ccl_init / the a2-links), so for
 // blob-like components the atomics drop from one per face to one per run pair.
-__global__ __launch_bounds__(256) void k_ccl_merge(const u8* __restrict__ member, i64 A0, i64 A1, i64 A2, int* parent) {
+__global__ __launch_bounds__(256) void k_ccl_merge(const u8* __restrict__ member, i64 A0, i64 A1, i64 A2, pb3d_magic m2, pb3d_magic m1, int* parent) {
     const i64 n = A0 * A1 * A2;
     for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (i64)gridDim.x * blockDim.x) {
         if (!member[v]) continue;
-        const i64 a2 = v % A2, r = v / A2, a1 = r % A1, a0 = r / A1;
+        const u32 r = pb3d_div((u32)v, m2), a2 = (u32)v - r * m2.d, a0 = pb3d_div(r, m1), a1 = r - a0 * m1.d;     // n < 2^31
         const bool back = a2 > 0 && member[v - 1];
         if (a2 + 1 < A2 && (v & 63) == 63 && member[v + 1]) uf_union(parent, (int)v, (int)(v + 1));   // only across init's segments
         if (a1 + 1 < A1 && member[v + A2] && !(back && member[v + A2 - 1])) uf_union(parent, (int)v, (int)(v + A2));
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void k_ccl_relabel(const int* __restrict__ roo
 // set of global atomics per label per block.  A label that does not fit the table goes straight to global memory.
 constexpr int kStatSlots = 16;
 
-__global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labels, i64 A0, i64 A1, i64 A2, int* __restrict__ bbox,
-                                                    unsigned long long* __restrict__ cnt_sum) {
+__global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labels, i64 A0, i64 A1, i64 A2, pb3d_magic m2, pb3d_magic m1,
+                                                    int* __restrict__ bbox, unsigned long long* __restrict__ cnt_sum) {
     __shared__ int slab[kStatSlots];
     __shared__ int slo[kStatSlots][3], shi[kStatSlots][3];
     __shared__ unsigned long long scs[kStatSlots][4];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labe
         int c[3] = {0, 0, 0};
         if (v < n) {
             L = labels[v];
-            if (L > 0) { c[2] = (int)(v % A2); const i64 r = v / A2; c[1] = (int)(r % A1); c[0] = (int)(r / A1); }
+            if (L > 0) { const u32 r = pb3d_div((u32)v, m2), q = pb3d_div(r, m1); c[2] = (int)((u32)v - r * m2.d); c[1] = (int)(r - q * m1.d); c[0] = (int)q; }
         }
         u64 todo = __ballot(L > 0);
         while (todo) {
@@ -324,10 +324,11 @@ int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, i
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)n * sizeof(int), &parent));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)n, &flag));
     const unsigned blocks = pb3d_stream_blocks(ctx, n, 256, 8);
-    hipLaunchKernelGGL(k_ccl_init, dim3(blocks), dim3(256), 0, ctx->stream, d_grid_rgb, n, A2, color[0], color[1], color[2], (int*)parent,
+    hipLaunchKernelGGL(k_ccl_init, dim3(blocks), dim3(256), 0, ctx->stream, d_grid_rgb, n, pb3d_make_magic((u32)A2), color[0], color[1], color[2], (int*)parent,
                        (u8*)flag);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_merge, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)flag, A0, A1, A2, (int*)parent);
+    hipLaunchKernelGGL(k_ccl_merge, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)flag, A0, A1, A2, pb3d_make_magic((u32)A2), pb3d_make_magic((u32)A1),
+                       (int*)parent);
     PB3D_CHECK_LAUNCH();
     // flag values after the flatten: 0 none, 1 root, 2 member; rootimg holds the roots only (what the ordered compaction selects)
     void *roots, *rootimg;
@@ -359,6 +360,7 @@ int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0,
     if (ncomp == 0) return PB3D_OK;
     PB3D_REQUIRE(d_labels && bbox_lo_hi && count && coord_sum, "pb3d_component_stats: null buffer");
     const i64 n = A0 * A1 * A2;
+    PB3D_REQUIRE(n < (1ll << 31), "pb3d_component_stats: grid too large for 32-bit labels");
     void *bb, *cs;
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)ncomp * 6 * sizeof(int), &bb));
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)ncomp * 4 * sizeof(unsigned long long), &cs));
@@ -371,7 +373,8 @@ int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0,
     free(hb);
     PB3D_HIP(e);
     PB3D_HIP(hipMemsetAsync(cs, 0, (size_t)ncomp * 4 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k_comp_stats, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_labels, A0, A1, A2, (int*)bb,
+    hipLaunchKernelGGL(k_comp_stats, dim3(pb3d_stream_blocks(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, d_labels, A0, A1, A2, pb3d_make_magic((u32)A2),
+                       pb3d_make_magic((u32)A1), (int*)bb,
                        (unsigned long long*)cs);
     PB3D_CHECK_LAUNCH();
     int* hbb = (int*)malloc((size_t)ncomp * 6 * sizeof(int));

@@ -105,14 +105,35 @@ static inline unsigned pb3d_stream_blocks(const pb3d_ctx* ctx, i64 work_items, i
     return (unsigned)(need < cap ? need : cap);
 }
 
+// ---- exact u32 division by a run-time constant (Granlund-Montgomery round-up form): q = (t + ((n - t) >> sa)) >> sb, t = mulhi(m, n).
+// A 64-bit integer division is ~100 vector instructions on gfx950 and the VALU issues one wave instruction per four cycles: kernels
+// that turn a linear voxel index into coordinates with / and % are bound by exactly that.
+struct pb3d_magic { u32 m; int sa, sb; u32 d; };
+static inline pb3d_magic pb3d_make_magic(u32 d) {     // 1 <= d < 2^31
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    pb3d_magic g;
+    g.m = (u32)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    g.sa = L < 1 ? L : 1;
+    g.sb = L > 1 ? L - 1 : 0;
+    g.d = d;
+    return g;
+}
+__device__ __forceinline__ u32 pb3d_div(u32 n, const pb3d_magic g) {
+    const u32 t = __umulhi(g.m, n);
+    return (t + ((n - t) >> g.sa)) >> g.sb;
+}
+
 // ---- kernels' host launchers used across translation units ---------------------------------
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
                                const double off[3], const u8* d_mask_wh, u8* d_out, const u8* d_mask_src);
+int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3], const u8* d_mask_wh, const u8* d_rgb_hw3,
+                           u8* d_out);
 bool pb3d_generic_step_takes_src_mask(const double M[9], i64 W, i64 H, i64 D);
 bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D);
 bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b);
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
-                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out);
+                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out, const u8* d_rgb_hw3 = nullptr);
 int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
                           const int* job_angle, const int* job_skip, int njobs, u8* d_out);
 int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh);

@@ -267,17 +267,21 @@ __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ g
 // base (a0,a1,a2) plus the local index with exact multiply-high divisions (no integer divide in the loop), colour
 // bytes leave as whole dwords cut out of two neighbouring 24-bit records (C == 1: four one-byte records per dword).
 // SINGLE = true: the one-pass form for resident callers (pb3d_points_extract_dev).  There is no count pass and no scanned
-// offset table: a workgroup takes a ticket (its place in the output order: tickets are handed out in start order, so every
-// predecessor is running or finished), counts its own selection, publishes it, and obtains the sum of its predecessors by a
+// offset table: a workgroup counts its own selection, publishes it, and obtains the sum of its predecessors (blockIdx order) by a
 // decoupled look-back over 64-bit status words (flag << 62 | value; flag 1 = this block's count, 2 = inclusive prefix).  A status
 // word is complete in itself, so relaxed agent-scope atomics are the whole protocol (no data is handed over behind it).
+// Ordering: a block only ever waits for blocks with SMALLER ids.  The dispatcher deals blocks to the XCDs round-robin and each XCD
+// starts its share in increasing order, so the smallest unfinished id is always resident and waits for nobody: the chain drains.
+// (A ticket counter would make that a theorem instead of an observation, but 262 144 atomics on one address cost 2.6 ms at
+// 1024^3 -- more than the whole pass.)  HIP promises no dispatch order, so every spin is BOUNDED: a block that gives up publishes a
+// poison word (flag 3), everyone behind it aborts at once, and the host falls back to the two-pass protocol.
 struct ScanState {
     unsigned long long* status;     // one word per block, zeroed before the launch
-    u32* ticket;                    // zeroed before the launch
-    i64* total;                     // out: number of selected voxels
+    i64* total;                     // out: number of selected voxels, or -1 when the look-back was abandoned
     i64 capacity;                   // rows the output buffers can take; blocks that would write past it write nothing
 };
-constexpr unsigned long long kFlagA = 1ull << 62, kFlagP = 2ull << 62, kValMask = (1ull << 62) - 1;
+constexpr unsigned long long kFlagA = 1ull << 62, kFlagP = 2ull << 62, kFlagX = 3ull << 62, kValMask = (1ull << 62) - 1;
+constexpr int kSpinLimit = 1 << 22;   // ~ seconds: far beyond any legitimate wait (a predecessor's count takes microseconds)
 
 template <int C, bool SINGLE>
 __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
@@ -287,12 +291,10 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     __shared__ unsigned short lidx[kBlockVox];
     __shared__ u32 lrec[kBlockVox + 1];
     __shared__ i64 sh_excl;
-    __shared__ u32 sh_bid;
     htab[threadIdx.x] = p.htab[threadIdx.x];
-    if (SINGLE && threadIdx.x == 0) sh_bid = atomicAdd(st.ticket, 1u);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u32 bid = SINGLE ? sh_bid : blockIdx.x;
+    const u32 bid = blockIdx.x;
     const i64 base = (i64)bid * kBlockVox;
     const i64 v0 = base + 16 * threadIdx.x;
     u32 w[12];
@@ -305,29 +307,63 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     u32 k = inc - c;
     for (int q = 0; q < wv; ++q) k += wsum[q];
     const u32 total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (SINGLE && wv == 0) {
-        // publish this block's count at once, then look back (wave 0, 64 predecessors per round, nearest predecessor in lane 0)
-        if (lane == 0) __hip_atomic_store(&st.status[bid], (bid == 0 ? kFlagP : kFlagA) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (SINGLE) {
+        // Publish this block's count at once, then look back with the WHOLE workgroup: 1024 predecessors per round (four status
+        // words per lane, nearest first), because with ~1500 blocks in flight the nearest inclusive prefix is that far back and a
+        // round trip to another XCD's flag costs microseconds -- a one-wave walk of 64 per round waited longer than the block
+        // takes to do its work.  Wave w owns the predecessors 256 w .. 256 w + 255 behind the block; each wave reduces its own
+        // slice (sum up to and including its first inclusive prefix), lane 0 of wave 0 combines the four in order.
+        __shared__ i64 part_sum[4];
+        __shared__ int part_stop[4];          // 1: this wave's slice held an inclusive prefix; 2: poison
+        if (threadIdx.x == 0) __hip_atomic_store(&st.status[bid], (bid == 0 ? kFlagP : kFlagA) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         i64 excl = 0;
-        i64 j = (i64)bid - 1;
-        while (j >= 0) {
-            const i64 idx = j - lane;
-            unsigned long long s = kFlagP;                        // lanes past block 0 contribute an empty prefix
-            if (idx >= 0) {
-                do { s = __hip_atomic_load(&st.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(s >> 62)) __builtin_amdgcn_s_sleep(1); } while (!(s >> 62));
+        bool poisoned = false, found = bid == 0;
+        for (i64 j0 = (i64)bid - 1; !found && !poisoned; j0 -= 1024) {
+            i64 wsum_ = 0;
+            int wstop = 0;
+            // the four status words of this lane are requested together (one round trip, not four); only words that are still
+            // empty are polled again
+            unsigned long long sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i64 idx = j0 - 256 * wv - 64 * q - lane;
+                sv[q] = idx >= 0 ? __hip_atomic_load(&st.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagP;   // past block 0: an empty prefix
             }
-            const u64 pm = __ballot((s >> 62) == 2ull);
-            const int stop = pm ? __builtin_ctzll(pm) : 64;        // first lane that holds an inclusive prefix ends the walk
-            i64 v = lane <= stop ? (i64)(s & kValMask) : 0;
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            excl += v;
-            if (pm) break;
-            j -= 64;
+#pragma unroll
+            for (int q = 0; q < 4 && !wstop; ++q) {
+                const i64 idx = j0 - 256 * wv - 64 * q - lane;
+                unsigned long long s_ = sv[q];
+                int spins = 0;
+                while (!(s_ >> 62)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    s_ = ++spins > kSpinLimit ? kFlagX : __hip_atomic_load(&st.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (__ballot((s_ >> 62) == 3ull)) { wstop = 2; break; }
+                const u64 pm = __ballot((s_ >> 62) == 2ull);
+                const int stop = pm ? __builtin_ctzll(pm) : 64;
+                i64 v = lane <= stop ? (i64)(s_ & kValMask) : 0;
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                wsum_ += v;
+                if (pm) wstop = 1;
+            }
+            if (lane == 0) { part_sum[wv] = wsum_; part_stop[wv] = wstop; }
+            __syncthreads();
+            for (int w2 = 0; w2 < 4; ++w2) {                       // every thread forms the same combination
+                if (part_stop[w2] == 2) { poisoned = true; break; }
+                excl += part_sum[w2];
+                if (part_stop[w2] == 1) { found = true; break; }
+            }
+            __syncthreads();
         }
-        if (lane == 0) {
-            if (bid != 0) __hip_atomic_store(&st.status[bid], kFlagP | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_excl = excl;
-            if (base + kBlockVox >= p.nlat) *st.total = excl + total;          // the last block knows the grand total
+        if (threadIdx.x == 0) {
+            if (poisoned) {
+                __hip_atomic_store(&st.status[bid], kFlagX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *st.total = -1;
+            } else {
+                if (bid != 0) __hip_atomic_store(&st.status[bid], kFlagP | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (base + kBlockVox >= p.nlat) *st.total = excl + total;      // the last block knows the grand total
+            }
+            sh_excl = poisoned ? -1 : excl;
         }
     }
 #pragma unroll
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     }
     __syncthreads();
     const i64 out0 = SINGLE ? sh_excl : block_off[blockIdx.x];
-    if (SINGLE && out0 + total > st.capacity) return;              // the caller's buffers are too small: write nothing past them
+    if (SINGLE && (out0 < 0 || out0 + total > st.capacity)) return;   // abandoned, or the caller's buffers are too small: write nothing
     // block base -> (b0, b1, b2); uniform, once per thread
     u32 b2, b1; i64 b0;
     if (p.nlat <= 0xffffffffll) {
@@ -354,16 +390,36 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
         const i64 r = base / p.A2;
         b2 = (u32)(base - r * p.A2); b0 = r / p.A1; b1 = (u32)(r - b0 * p.A1);
     }
-    float* po = pts + 3 * out0;
-    for (u32 pt = threadIdx.x; pt < total; pt += 256) {
-        const u32 x = b2 + lidx[pt];                               // < A2 + 4096
-        const u32 q2 = magic_div(x, p.m2, p.s2a, p.s2b);
-        const u32 a2 = x - q2 * (u32)p.A2;
-        const u32 y = b1 + q2;                                      // < A1 + 4096
-        const u32 q1 = magic_div(y, p.m1, p.s1a, p.s1b);
-        const u32 a1 = y - q1 * (u32)p.A1;
-        const i64 a0 = b0 + q1;
-        po[3 * pt] = (float)a2; po[3 * pt + 1] = (float)a1; po[3 * pt + 2] = (float)a0;
+    // Points leave as whole 16-byte vectors: a dword store per float at a 12-byte stride touches every 128-byte line with three
+    // instructions of 16-of-48 bytes each (what bounded this kernel); the coordinates of 512 points at a time are staged in LDS at
+    // the phase of the output address, so that an LDS piece IS an aligned 16-byte piece of the output.  Only the first and last
+    // piece of a chunk are partial (scalar stores of the floats that belong to this block).
+    __shared__ __attribute__((aligned(16))) float lp[4 + 3 * 512 + 4];
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    for (u32 c0 = 0; c0 < total; c0 += 512) {
+        const u32 nc = total - c0 < 512u ? total - c0 : 512u;
+        float* gfirst = pts + 3 * (out0 + c0);                          // first float of this chunk
+        const u32 shift = (u32)(((uintptr_t)gfirst >> 2) & 3u);          // floats past a 16-byte boundary
+        for (u32 q = threadIdx.x; q < nc; q += 256) {
+            const u32 x = b2 + lidx[c0 + q];                            // < A2 + 4096
+            const u32 q2 = magic_div(x, p.m2, p.s2a, p.s2b);
+            const u32 a2 = x - q2 * (u32)p.A2;
+            const u32 y = b1 + q2;                                      // < A1 + 4096
+            const u32 q1 = magic_div(y, p.m1, p.s1a, p.s1b);
+            const u32 a1 = y - q1 * (u32)p.A1;
+            const i64 a0 = b0 + q1;
+            float* l = lp + shift + 3 * q;
+            l[0] = (float)a2; l[1] = (float)a1; l[2] = (float)a0;
+        }
+        __syncthreads();
+        float* gbase = gfirst - shift;                                  // 16-byte aligned; lp[i] <-> gbase[i]
+        const u32 nfl = shift + 3 * nc;
+        for (u32 pz = threadIdx.x; 4 * pz < nfl; pz += 256) {
+            const u32 f0 = 4 * pz < shift ? shift : 4 * pz, f1 = 4 * pz + 4 < nfl ? 4 * pz + 4 : nfl;
+            if (f1 - f0 == 4) *(f32x4v*)(gbase + 4 * pz) = *(const f32x4v*)(lp + 4 * pz);
+            else for (u32 f = f0; f < f1; ++f) gbase[f] = lp[f];
+        }
+        __syncthreads();
     }
     // colours: head bytes up to the first dword boundary of the output, then whole dwords, then the tail
     u8* co = cols + C * out0;
@@ -517,7 +573,6 @@ int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, in
     PB3D_HIP(hipMemsetAsync(stv, 0, (size_t)nb * sizeof(unsigned long long) + 64, ctx->stream));
     ScanState st;
     st.status = (unsigned long long*)((u8*)stv + 64);
-    st.ticket = (u32*)stv;
     st.total = (i64*)((u8*)stv + 8);
     st.capacity = capacity;
     if (C == 1) hipLaunchKernelGGL((k_points_fill16<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st);
@@ -526,6 +581,11 @@ int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, in
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, st.total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));
     *n = *(i64*)ctx->pinned;
+    if (*n < 0) {          // the look-back was abandoned (a dispatch order this code does not expect): nothing hung, nothing was written
+        *n = 0;
+        pb3d_set_error("pb3d_points_extract: look-back abandoned; use pb3d_points_count / pb3d_points_fill");
+        return PB3D_EUNSUPPORTED;
+    }
     return PB3D_OK;
 }
 

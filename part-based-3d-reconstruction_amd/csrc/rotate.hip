@@ -330,31 +330,37 @@ struct CellRec { u32 src, lut; };      // src = s0 << 16 | s2 (0xffffffff: outsi
 
 __global__ __launch_bounds__(256) void k_rot_cells(RotParams p, i64 W, i64 D, CellRec* __restrict__ cells, u32* __restrict__ lutmap) {
     // lutmap (optional, 512 words, zeroed by the launcher): bit t is set when some cell's table bits 1..14 equal t -- a rotation
-    // produces about a dozen distinct tables, which lets the packed kernel keep a 4-bit index per cell (k_rot8_pack)
+    // produces about a dozen distinct tables, which lets the packed kernel keep a 4-bit index per cell (k_rot8_pack).
+    // Four cells per thread (1024 per block): the per-block flush of the bitmap is what this kernel's time consists of.
     __shared__ u32 seen[512];
     if (lutmap) { seen[threadIdx.x] = 0; seen[threadIdx.x + 256] = 0; __syncthreads(); }
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 tbl = 0xffffffffu;
-    if (i < W * D) {
-        const i64 x = i / D, z = i - x * D;
-        const Cell c = make_cell(p, x, z, W, D);
-        CellRec r; r.src = 0xffffffffu; r.lut = 0;
-        if (c.s0 >= 0) {
-            r.src = ((u32)c.s0 << 16) | (u32)c.s2;
-            r.lut = lut_of(c) | (c.wx1 != 0.0 ? 1u << 16 : 0u) | (c.wz1 != 0.0 ? 1u << 17 : 0u);
-            tbl = (r.lut >> 1) & 0x3fffu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const i64 i = ((i64)blockIdx.x * 4 + q) * 256 + threadIdx.x;
+        u32 tbl = 0xffffffffu;
+        if (i < W * D) {
+            const i64 x = i / D, z = i - x * D;
+            const Cell c = make_cell(p, x, z, W, D);
+            CellRec r; r.src = 0xffffffffu; r.lut = 0;
+            if (c.s0 >= 0) {
+                r.src = ((u32)c.s0 << 16) | (u32)c.s2;
+                r.lut = lut_of(c) | (c.wx1 != 0.0 ? 1u << 16 : 0u) | (c.wz1 != 0.0 ? 1u << 17 : 0u);
+                tbl = (r.lut >> 1) & 0x3fffu;
+            }
+            cells[i] = r;
         }
-        cells[i] = r;
+        if (lutmap) {
+            // a wave holds a handful of distinct tables: one LDS atomic per distinct value, not per lane
+            u64 todo = __ballot(tbl != 0xffffffffu);
+            while (todo) {
+                const int lead = __builtin_ctzll(todo);
+                const u32 tv = (u32)__shfl((int)tbl, lead);
+                if ((int)(threadIdx.x & 63) == lead) atomicOr(&seen[tv >> 5], 1u << (tv & 31));
+                todo &= ~__ballot(tbl == tv);
+            }
+        }
     }
     if (lutmap) {
-        // a wave holds a handful of distinct tables: one LDS atomic per distinct value, not per lane
-        u64 todo = __ballot(tbl != 0xffffffffu);
-        while (todo) {
-            const int lead = __builtin_ctzll(todo);
-            const u32 tv = (u32)__shfl((int)tbl, lead);
-            if ((int)(threadIdx.x & 63) == lead) atomicOr(&seen[tv >> 5], 1u << (tv & 31));
-            todo &= ~__ballot(tbl == tv);
-        }
         __syncthreads();
         for (int k = threadIdx.x; k < 512; k += 256)         // a dozen distinct tables in all: after the first blocks nothing is new
             if (seen[k] && (__hip_atomic_load(&lutmap[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & seen[k]) != seen[k]) atomicOr(&lutmap[k], seen[k]);
@@ -913,16 +919,14 @@ constexpr int PLDS_DATA = 76 * 1024;                // packed footprint, one byt
 constexpr int PMAXUNITS = PLDS_DATA / 16;           // 16-voxel units
 constexpr int PUPT = (PMAXUNITS + PTHREADS - 1) / PTHREADS;   // units per thread (10)
 constexpr int PPARTS = 8;                           // set-up: 32 x-rows of a tile per workgroup
-constexpr int PNOROW = (int)0x80000000;
 constexpr size_t kPLds = (size_t)PLDS_DATA + (PROWS + 1) * 4 + 16 * 4;
-constexpr size_t kPLdsPair = (size_t)2 * PLDS_DATA + (PROWS + 1) * 4 + 16 * 4;
 
 struct PPart { int bb[4]; int rmin[PROWS], rmax[PROWS]; };
 struct PTile {
     int bx0, nrows, nunits, fits;
     u32 dict[16];                     // the step's distinct 14-bit tables (bits 1..14 of SciPy's result table), ascending; ndict <= 15
     int ndict;
-    int atab[PROWS + 1];              // LDS byte of source voxel (row r, column s2) = atab[r] + s2 ; PNOROW: the row is not staged
+    int atab[PROWS + 1];              // LDS byte of source voxel (row r, column s2) = atab[r] + s2 (rows nobody stages: the row above)
     int start16[PROWS];               // first staged column of row r (multiple of 16)
     u32 voff[PMAXUNITS];              // voxel offset of unit i at plane 0: (bx0 + r) * H * D + start16[r] + 16 k
     unsigned short srow[PMAXUNITS];   // r of unit i
@@ -1050,7 +1054,12 @@ __global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict
     const bool fits = rows_fit && nunits <= PMAXUNITS && ndict <= 15;
     if (tid == 0) { ti->bx0 = bx0; ti->nrows = nrows; ti->nunits = fits ? nunits : 0; ti->fits = (fits || nrows == 0) ? 1 : 0; ti->ndict = ndict; }
     if (tid < 16) ti->dict[tid] = tid < ndict ? dict[tid] : 0xffffffffu;
-    if (tid <= PROWS) ti->atab[tid] = hi[tid] >= 0 ? 16 * ust[tid] - lo[tid] : PNOROW;
+    if (tid <= PROWS) {
+        // a row nobody stages is only ever addressed as an UNUSED x tap (weight 0): point it at the row above
+        int rr = tid;
+        while (rr > 0 && hi[rr] < 0) --rr;
+        ti->atab[tid] = hi[rr] >= 0 ? 16 * ust[rr] - lo[rr] : 0;
+    }
     if (tid < PROWS) ti->start16[tid] = lo[tid];
     if (fits) {
         for (int i = tid; i < nunits; i += PTHREADS) {            // unit i -> its row: the last r with ust[r] <= i
@@ -1150,22 +1159,19 @@ __device__ __forceinline__ u32 mask8(const u8* __restrict__ p, int np) {
     return bits;
 }
 
-// PAIR = false: 512 threads, one footprint buffer, two workgroups per CU (the hardware decides how their phases fall together).
-// PAIR = true : 1024 threads = two wave groups with a footprint buffer each, ONE workgroup per CU; the groups work on alternate
-//               passes of the plane chunk and are offset by one phase, so that between any two workgroup barriers one group
-//               STAGES (HBM reads, little VALU) while the other EVALUATES (LDS + VALU + stores) -- the pairing is by construction.
-template <bool SRCMASK, bool PAIR>
-__global__ __launch_bounds__(PAIR ? 2 * PTHREADS : PTHREADS, PAIR ? 1 : 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
+// 512 threads, two workgroups per CU (verified resident together: tools/kbench5.hip).  Tried and measured no better: one 1024-thread
+// workgroup whose two wave groups alternate stage / evaluate by construction, random start staggers, and a skewed cyclic walk of
+// the runs against LDS bank conflicts -- none of them moved the time, because the kernel was bound by VALU ISSUE (below).
+template <bool SRCMASK>
+__global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
                                                                const RunRec* __restrict__ runs, const PTile* __restrict__ tiles, i64 W, i64 H, i64 D,
                                                                int TY, int ntz, int ntiles, int nchunks, int* __restrict__ big_flag,
-                                                               const u8* __restrict__ mask_src, int abl, int skew16) {
-    extern __shared__ __attribute__((aligned(16))) u8 plds_all[];
-    int* atab = (int*)(plds_all + (PAIR ? 2 : 1) * PLDS_DATA);   // PROWS + 1 entries
+                                                               const u8* __restrict__ mask_src, int abl) {
+    extern __shared__ __attribute__((aligned(16))) u8 plds[];
+    int* atab = (int*)(plds + PLDS_DATA);              // PROWS + 1 entries
     u32* dict = (u32*)(atab + PROWS + 1);              // 16 entries
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const int group = PAIR ? (int)(threadIdx.x >> 9) : 0;           // wave-uniform
-    const int tid = (int)(threadIdx.x & (PTHREADS - 1));
-    u8* plds = plds_all + (size_t)group * PLDS_DATA;
+    const int tid = threadIdx.x;
     const int slot = (int)(blockIdx.x >> 3);
     const int t = slot % ntiles;
     const int chunk = (slot / ntiles) * 8 + (int)(blockIdx.x & 7u);
@@ -1177,10 +1183,8 @@ __global__ __launch_bounds__(PAIR ? 2 * PTHREADS : PTHREADS, PAIR ? 1 : 4) void 
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
     const int nunits = ti->nunits;
     const i64 bx0 = ti->bx0;
-    if (group == 0) {
-        for (int i = tid; i <= PROWS; i += PTHREADS) atab[i] = ti->atab[i];
-        if (tid < 16) dict[tid] = ti->dict[tid];
-    }
+    for (int i = tid; i <= PROWS; i += PTHREADS) atab[i] = ti->atab[i];
+    if (tid < 16) dict[tid] = ti->dict[tid];
     u32 uvoff[PUPT], usrow[(PUPT + 1) / 2];           // usrow: footprint row of unit j, two per register (source-mask form only)
 #pragma unroll
     for (int j = 0; j < (PUPT + 1) / 2; ++j) usrow[j] = 0;
@@ -1190,57 +1194,68 @@ __global__ __launch_bounds__(PAIR ? 2 * PTHREADS : PTHREADS, PAIR ? 1 : 4) void 
         uvoff[j] = i < nunits ? ti->voff[i] : 0xffffffffu;
         if (SRCMASK && i < nunits) usrow[j >> 1] |= (u32)ti->srow[i] << (16 * (j & 1));
     }
-    // This thread's 8 runs of 16 cells, in registers for the whole life of the workgroup.  A wave holds 16 consecutive x-rows
-    // (lane & 15) of 4 neighbouring runs (lane >> 4): run slot q of wave w is row group (8 q + w) >> 2, run group (8 q + w) & 3.
-    // Lanes of one row group walk their runs CYCLICALLY from a per-row start phase (skew), so that at every step the 16 lanes of a
-    // run group sit on an output diagonal whose source voxels share one footprint row: their tap reads fall into a few consecutive
-    // LDS dwords instead of 16 unrelated ones (bank conflicts were what bounded the evaluation).
-    const int wv_ = tid >> 6, jrow = tid & 15, krun = (tid >> 4) & 3;
-    const int phase = ((jrow * skew16) >> 4) & 15;
+    // This thread's 8 runs of 16 cells, in registers for the whole life of the workgroup: run slot k is x-row 32 k + tid / 16, cells
+    // 16 (tid % 16) .. + 15 (16 lanes cover one 256-byte output row).
+    const int zc = 16 * (tid & 15);
     u32x4 run[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int combo = 8 * k + wv_;
-        const i64 x = x0 + 16 * (combo >> 2) + jrow, z = z0 + 16 * (4 * (combo & 3) + krun);
+        const i64 x = x0 + 32 * k + (tid >> 4), z = z0 + zc;
         run[k] = (u32x4)(0u, 0u, 0xffffffffu, 0xffffffffu);
         if (x < W && z < D) run[k] = *(const u32x4*)(runs + x * (D / 16) + (z >> 4));
     }
     __syncthreads();
+    // dictionary entry e as the kernel wants it: table bits 1..7 in byte 0, bits 8..14 in byte 1, table bit 15 (= 1 for every real
+    // cell) in byte 2; entry 15 (void cells) = 0: an all-zero table evaluates to 0 whatever the taps are
+    if (tid < 16) {
+        const u32 raw = dict[tid], t14 = raw & 0x3fffu;
+        dict[tid] = (tid == 15 || raw == 0xffffffffu) ? 0u : ((t14 & 0x7fu) | ((t14 >> 7) << 8) | (1u << 16));
+    }
+    const u32 voff_safe = nunits > 0 ? ti->voff[0] : 0u;          // what lanes without a unit load (and throw away)
+    __syncthreads();
     u32 hib = 0;
+    // The kernel is bound by VALU issue, not by HBM or LDS (SQ counters: 10 k vector instructions per wave and pass at one per four
+    // cycles were 60 % of its time), so both phases are written for instruction count: unconditional loads, one v_lshl_or per dword
+    // to bit-slice, and a table evaluation that serves FOUR cells per instruction.
     auto stage = [&](i64 yg) {
         const int np = (int)(y_end - yg < 8 ? y_end - yg : 8);
-        // ---- stage the footprint of 8 planes: 16 voxels x 8 planes per unit, loaded as two halves of 4 planes; the next half's loads
-        //      are issued before this one is packed (8 x 16 B in flight per lane, 128 KB per CU)
+        if (nunits == 0 || (abl & 2)) return;
+        // 16 voxels x 8 planes per unit, loaded as two halves of 4 planes; the next half's loads are issued before this one is packed.
+        // Loads are never predicated: a lane without a unit re-reads unit 0, a plane past the chunk's end re-reads the last one (its
+        // bits land in plane slots that are never stored).  Data is 0/1 (anything else raises the flag and the step is redone), so
+        // "shift the dword by q and OR" bit-slices four voxels in one instruction.
         u32x4 d[2][4];
-        auto load_half = [&](u32x4 (&dd)[4], int hh) {           // hh = 2 * unit + half
+        auto load_half = [&](u32x4 (&dd)[4], int hh) {
             const int j = hh >> 1, q0 = 4 * (hh & 1);
-            const u32 voff = uvoff[j];
-            u32 msrc = 0xffu;
-            if (SRCMASK && voff != 0xffffffffu) msrc = mask8(mask_src + (u32)((bx0 + ((usrow[j >> 1] >> (16 * (j & 1))) & 0xffffu)) * H) + yg, np);
+            const u32 voff = uvoff[j] != 0xffffffffu ? uvoff[j] : voff_safe;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const u8* pb = in + (yg + q0 + q) * D;         // uniform
-                dd[q] = (u32x4)(0u);
-                if (voff != 0xffffffffu && q0 + q < np && ((msrc >> (q0 + q)) & 1u)) dd[q] = *(const u32x4*)(pb + voff);
+                const int qe = q0 + q < np ? q0 + q : np - 1;     // uniform
+                dd[q] = *(const u32x4*)(in + (yg + qe) * D + voff);
             }
         };
-        if (!(abl & 2)) load_half(d[0], 0);
+        load_half(d[0], 0);
         u32x4 wv = (u32x4)(0u);
 #pragma unroll
         for (int hh = 0; hh < 2 * PUPT; ++hh) {
-            if (abl & 2) break;
             if (hh + 1 < 2 * PUPT) load_half(d[(hh + 1) & 1], hh + 1);
+            __builtin_amdgcn_sched_barrier(0);                    // nothing is predicated any more: keep the scheduler from hoisting all 80 loads
             const int j = hh >> 1, q0 = 4 * (hh & 1);
-            if (uvoff[j] != 0xffffffffu) {
+            u32 msrc = 0xffu;
+            if (SRCMASK && uvoff[j] != 0xffffffffu) msrc = mask8(mask_src + (u32)((bx0 + ((usrow[j >> 1] >> (16 * (j & 1))) & 0xffffu)) * H) + yg, np);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4 dd = d[hh & 1][q];
-                    wv.x |= (dd.x & 0x01010101u) << (q0 + q); wv.y |= (dd.y & 0x01010101u) << (q0 + q);
-                    wv.z |= (dd.z & 0x01010101u) << (q0 + q); wv.w |= (dd.w & 0x01010101u) << (q0 + q);
-                    hib |= dd.x | dd.y | dd.z | dd.w;
-                }
-                if (hh & 1) { *(u32x4*)(plds + 16 * (tid + PTHREADS * j)) = wv; wv = (u32x4)(0u); }
+            for (int q = 0; q < 4; ++q) {
+                u32x4 dd = d[hh & 1][q];
+                if (SRCMASK && !((msrc >> (q0 + q)) & 1u)) dd = (u32x4)(0u);      // the folded 0-degree carve: this source row / plane is dropped
+                wv.x |= dd.x << (q0 + q); wv.y |= dd.y << (q0 + q); wv.z |= dd.z << (q0 + q); wv.w |= dd.w << (q0 + q);
+                hib |= (dd.x | dd.y) | (dd.z | dd.w);
             }
+            asm volatile("" : "+v"(hib));                         // fold the check in HERE: left alone, the scheduler keeps all 80 vectors alive for it
+            if (hh & 1) {
+                if (uvoff[j] != 0xffffffffu) *(u32x4*)(plds + 16 * (tid + PTHREADS * j)) = wv;
+                wv = (u32x4)(0u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto evaluate = [&](i64 yg) {
@@ -1250,80 +1265,67 @@ __global__ __launch_bounds__(PAIR ? 2 * PTHREADS : PTHREADS, PAIR ? 1 : 4) void 
 #pragma unroll 1
         for (int qq = 0; qq < 8; ++qq) {
             if (abl & 1) break;
-            // A run is decoded branch-free, four cells at a time, starting at cell `phase` and wrapping: the position of the start
-            // cell is the run's base plus the row / column steps below it (two popcounts), then every cell takes its own step -- or
-            // returns to the base when the walk wraps to cell 0.  Per group: all row-table reads, then the 16 tap reads, then the
-            // four table evaluations (an LDS round trip per group, not per cell).
+            // Four cells at a time (rolled loop, one group's registers live): positions by the run's step bits, one row-table read
+            // pair and one dictionary read per cell, 16 tap bytes -- then the taps of the four cells are packed bytewise into four
+            // dwords and SciPy's table is applied to all four cells x 8 planes at once: mask L_k has byte c = 0xff where cell c's
+            // table bit k is set (v_perm with selector bytes 0x0c / 0x0d), and the 15-select multiplexer tree runs once per group.
             const u32x4 rec = run[0];
-            const int r0 = (int)(rec.x & 511u);
-            const u32 s20 = rec.x >> 9, drb = rec.y & 0xffffu, dcb = rec.y >> 16;
-            const u32 below = (2u << phase) - 2u;                                       // steps into cells 1 .. phase
-            int r = r0 - __popc(drb & below);
-            u32 s2 = s20 + (u32)__popc(dcb & below);
-            const unsigned long long kw = ((unsigned long long)rec.w << 32) | rec.z;    // 16 x 4-bit table indices
-            u32 G0 = 0, G1 = 0, G2 = 0, G3 = 0;
-            int ci = phase;
+            int r = (int)(rec.x & 511u);
+            u32 s2 = rec.x >> 9;
+            u32 G[4];
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
-                int rc[4]; u32 sc[4], kc[4];
+                const u32 wd = rec.y >> (4 * i), wk = (i < 2 ? rec.z : rec.w) >> (16 * (i & 1));
+                u32 o0[4], o1[4], lt[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (i | c) {                                                         // the start cell's position is already set
-                        ci = (ci + 1) & 15;
-                        const bool wrap = ci == 0;
-                        r = wrap ? r0 : r - (int)((drb >> ci) & 1u);                    // void cells carry no step bits
-                        s2 = wrap ? s20 : s2 + ((dcb >> ci) & 1u);
-                    }
-                    kc[c] = (u32)(kw >> (4 * ci)) & 15u;
-                    rc[c] = r; sc[c] = s2;
+                    r -= (int)((wd >> c) & 1u); s2 += (wd >> (16 + c)) & 1u;            // void cells carry no step bits
+                    const int* ap = atab + r;
+                    o0[c] = (u32)ap[0] + s2; o1[c] = (u32)ap[1] + s2;
+                    lt[c] = dict[(wk >> (4 * c)) & 15u];
                 }
-                int a0[4], a1[4]; u32 lt[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { a0[c] = atab[rc[c]]; a1[c] = atab[rc[c] + 1]; lt[c] = dict[kc[c]]; }
                 u32 tp[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool live = kc[c] != 15u;
-                    const u32 o0 = live ? (u32)a0[c] + sc[c] : 0u;
-                    const u32 o1 = (live && a1[c] != PNOROW) ? (u32)a1[c] + sc[c] : o0;     // unused x tap: any staged byte will do
-                    tp[c][0] = plds[o0]; tp[c][1] = plds[o0 + 1]; tp[c][2] = plds[o1]; tp[c][3] = plds[o1 + 1];
-                }
-                u32 R[4];
+                for (int c = 0; c < 4; ++c) { tp[c][0] = plds[o0[c]]; tp[c][1] = plds[o0[c] + 1]; tp[c][2] = plds[o1[c]]; tp[c][3] = plds[o1[c] + 1]; }
+                u32 T[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    R[c] = lut_apply14(lt[c], tp[c][0], tp[c][1], tp[c][2], tp[c][3]);
-                    R[c] = kc[c] != 15u ? R[c] : 0u;
+                for (int t = 0; t < 4; ++t) T[t] = tp[0][t] | (tp[1][t] << 8) | (tp[2][t] << 16) | (tp[3][t] << 24);
+                const u32 PL = pperm(lt[1], lt[0], 0x0c0c0400u) | (pperm(lt[3], lt[2], 0x0c0c0400u) << 16);     // table bits 1..7 of the 4 cells
+                const u32 PH = pperm(lt[1], lt[0], 0x0c0c0501u) | (pperm(lt[3], lt[2], 0x0c0c0501u) << 16);     // table bits 8..14
+                const u32 PX = pperm(lt[1], lt[0], 0x0c0c0602u) | (pperm(lt[3], lt[2], 0x0c0c0602u) << 16);     // table bit 15: 1 = real cell
+                // L_k: byte c = 0xff where cell c's table bit k is set, in TWO instructions: isolate the bit in every byte (values 0
+                // or 1 << j) and let v_perm read it as a byte selector against (S0, S1) = (0x000000ff, 0x00ffff00): selector 0 picks
+                // S1.byte0 = 0x00; 1, 2 pick S1.byte1/2 = 0xff; 4 picks S0.byte0 = 0xff; 8 replicates the sign of S1.byte1 = 0xff;
+                // 16, 32, 64 (>= 13) are the constant 0xff
+                u32 L[16];
+                L[0] = 0u; L[15] = pperm(0x000000ffu, 0x00ffff00u, PX);
+#pragma unroll
+                for (int k = 1; k < 15; ++k) {
+                    const int j = k <= 7 ? k - 1 : k - 8;
+                    L[k] = pperm(0x000000ffu, 0x00ffff00u, (k <= 7 ? PL : PH) & (0x01010101u << j));
                 }
-                const u32 l01 = pperm(R[1], R[0], 0x0c0c0400u), l23 = pperm(R[3], R[2], 0x0c0c0400u);   // byte 0 of each pair
-                G0 = G1; G1 = G2; G2 = G3; G3 = l01 | (l23 << 16);                 // after four groups: bytes in WALK order
+                u32 g[8], h4[4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = bsel(T[0], L[2 * j + 1], L[2 * j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h4[j] = bsel(T[1], g[2 * j + 1], g[2 * j]);
+                const u32 m0 = bsel(T[2], h4[1], h4[0]), m1 = bsel(T[2], h4[3], h4[2]);
+                const u32 Gn = bsel(T[3], m1, m0);                                     // byte c = the 8 planes of cell 4 i + c
+                G[0] = G[1]; G[1] = G[2]; G[2] = G[3]; G[3] = Gn;
             }
-            // walk order -> cell order: byte n of (G0..G3) belongs to cell (phase + n) & 15, i.e. rotate the 16 bytes left by `phase`
-            {
-                const u32 sh = (u32)(phase & 3);
-                // out dword m, byte b  <-  walk byte (4 m + b - phase) & 15
-                const u32 t0 = __builtin_amdgcn_alignbyte(G0, G3, 4u - sh), t1 = __builtin_amdgcn_alignbyte(G1, G0, 4u - sh),
-                          t2 = __builtin_amdgcn_alignbyte(G2, G1, 4u - sh), t3 = __builtin_amdgcn_alignbyte(G3, G2, 4u - sh);
-                const u32 u0 = sh ? t0 : G0, u1 = sh ? t1 : G1, u2 = sh ? t2 : G2, u3 = sh ? t3 : G3;    // alignbyte by 4 is not the identity
-                const int dq = phase >> 2;                                                       // whole dwords
-                G0 = dq == 0 ? u0 : (dq == 1 ? u3 : (dq == 2 ? u2 : u1));
-                G1 = dq == 0 ? u1 : (dq == 1 ? u0 : (dq == 2 ? u3 : u2));
-                G2 = dq == 0 ? u2 : (dq == 1 ? u1 : (dq == 2 ? u0 : u3));
-                G3 = dq == 0 ? u3 : (dq == 1 ? u2 : (dq == 2 ? u1 : u0));
-            }
-            const int combo = 8 * qq + wv_;
-            const i64 x = x0 + 16 * (combo >> 2) + jrow;
-            const i64 z = z0 + 16 * (4 * (combo & 3) + krun);
+            const i64 x = x0 + 32 * qq + (tid >> 4);
+            const i64 z = z0 + zc;
             if (x < W && z < D) {
                 const u32 mbits = mask_wh ? mask8(mask_wh + x * H + yg, np) : 0xffu;
+                const u32 mk = mbits * 0x01010101u;                                    // the row's plane mask in every byte
+                const u32 A0 = G[0] & mk, A1 = G[1] & mk, A2 = G[2] & mk, A3 = G[3] & mk;
                 const u32 ooff = (u32)(x * H * D + z);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (q >= np) break;
-                    const u32 keep = ((mbits >> q) & 1u) ? 0x01010101u : 0u;
                     u32x4 rr;
-                    rr.x = (G0 >> q) & keep; rr.y = (G1 >> q) & keep; rr.z = (G2 >> q) & keep; rr.w = (G3 >> q) & keep;
-                    u8* pb = out + (yg + q) * D;                          // uniform
-                    *(u32x4*)(pb + ooff) = rr;
+                    rr.x = (A0 >> q) & 0x01010101u; rr.y = (A1 >> q) & 0x01010101u; rr.z = (A2 >> q) & 0x01010101u; rr.w = (A3 >> q) & 0x01010101u;
+                    *(u32x4*)(out + (yg + q) * D + ooff) = rr;
                 }
             }
             const u32x4 t0 = run[0];
@@ -1332,31 +1334,107 @@ __global__ __launch_bounds__(PAIR ? 2 * PTHREADS : PTHREADS, PAIR ? 1 : 4) void 
             run[7] = t0;
         }
     };
-    if (!PAIR) {
-        for (i64 yg = y_beg; yg < y_end; yg += 8) {
-            stage(yg);
-            __syncthreads();
-            evaluate(yg);
-            __syncthreads();
-        }
-    } else {
-        // group g owns the passes g, g + 2, ... of the chunk; group 1 runs one phase behind group 0.  Every wave executes the same
-        // number of barriers: a phase is [one group stages | the other evaluates] between two of them.
-        const i64 npass = (y_end - y_beg + 7) / 8;
-        const i64 mine = (npass + 1 - group) / 2;               // passes of this group
-        const i64 phases = 2 * ((npass + 1) / 2) + ((npass & 1) ? 0 : 1);     // group 0: 2 * ceil(n/2); group 1: 1 + 2 * floor(n/2)
-        i64 done = 0;
-        if (group == 1) { __syncthreads(); ++done; }
-        for (i64 k = 0; k < mine; ++k) {
-            const i64 yg = y_beg + 8 * (group + 2 * k);
-            stage(yg);
-            __syncthreads(); ++done;
-            evaluate(yg);
-            __syncthreads(); ++done;
-        }
-        for (; done < phases; ++done) __syncthreads();
+    for (i64 yg = y_beg; yg < y_end; yg += 8) {
+        stage(yg);
+        __syncthreads();
+        evaluate(yg);
+        __syncthreads();
     }
     if (hib & 0xfefefefeu) atomicOr(big_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// First rotation step of global_carve (reference utils/voxel_carving_utils.py:279-292) with its source SYNTHESISED: the grid that
+// step sees is carve(ones, mask) -- every source voxel (s0, y, s2) equals bm[s0, y], whatever s2 -- so nothing is read from HBM but
+// the cell table: the four taps of a cell are (b0, b0, b1, b1) with b0 = bm[s0, y], b1 = bm[s0 + 1, y], and SciPy's 16-entry result
+// table collapses to three entries (tap patterns 0011, 1100, 1111).  The masks of 32 planes are held per x-row as one dword in LDS
+// (bit q = bm[x, y0 + q]); a cell's 32 planes are three bitwise selects.  RGBOUT: the step is also the LAST one (angle_interval 46..90
+// without 90, e.g. 60): the colours rgb[y, x] are written instead of the occupancy -- the whole global_carve is then write-only.
+// One thread = one run of 16 cells along z (D % 16 == 0); 16 lanes cover 256 contiguous output bytes (768 with colours).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rgb_of_occ4(u32 occ01, u32 C0, u32 C1, u32 C2, u32* o) {     // 4 occupancy bytes (0/1) -> 12 colour bytes
+    const u32 e = occ01 * 0xffu;                                                              // bytes 0x00 / 0xff (no carries)
+    o[0] = pperm(e, e, 0x01000000u) & C0; o[1] = pperm(e, e, 0x02020101u) & C1; o[2] = pperm(e, e, 0x03030302u) & C2;
+}
+
+// bits[c * W + x]: bit q = mask_wh[x, 32 c + q] != 0 -- the (W,H) mask as one dword per x-row and chunk of 32 planes
+__global__ __launch_bounds__(256) void k_mask_planebits(const u8* __restrict__ mask_wh, i64 W, i64 H, u32* __restrict__ bits) {
+    const i64 nch = (H + 31) / 32;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nch * W; i += (i64)gridDim.x * blockDim.x) {
+        const i64 c = i / W, x = i - c * W, y0 = 32 * c;
+        u32 b = 0;
+        for (int q = 0; q < 32 && y0 + q < H; ++q) b |= (u32)(mask_wh[x * H + y0 + q] != 0) << q;
+        bits[i] = b;
+    }
+}
+
+template <bool RGBOUT>
+__global__ __launch_bounds__(256) void k_first_step(const CellRec* __restrict__ cells, const u32* __restrict__ planebits, const u8* __restrict__ rgb_hw3,
+                                                    i64 W, i64 H, i64 D, u8* __restrict__ out) {
+    extern __shared__ u32 mb[];                         // W dwords: bit q = mask_wh[x, y0 + q]
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const i64 y0 = (i64)blockIdx.y * 32;
+    const int np = (int)(H - y0 < 32 ? H - y0 : 32);
+    for (i64 x = threadIdx.x; x < W; x += 256) mb[x] = planebits[(i64)blockIdx.y * W + x];
+    __syncthreads();
+    const i64 nzr = D / 16;
+    const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (g >= W * nzr) return;
+    const i64 x = g / nzr, z0 = 16 * (g - x * nzr);
+    const u32 dst = mb[x];
+    u32 bits[16];
+    const u32x4* cp = (const u32x4*)(cells + x * D + z0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u32x4 v = cp[k];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 src = h ? v.z : v.x, lut = h ? v.w : v.y;
+            u32 r = 0;
+            if (src != 0xffffffffu) {
+                const u32 s0 = src >> 16;
+                const u32 B0 = mb[s0], B1 = s0 + 1 < (u32)W ? mb[s0 + 1] : 0u;       // beyond the grid the tap has weight 0: the table ignores it
+                const u32 E1 = (u32)__builtin_amdgcn_sbfe((int)lut, 3, 1), E2 = (u32)__builtin_amdgcn_sbfe((int)lut, 12, 1),
+                          E3 = (u32)__builtin_amdgcn_sbfe((int)lut, 15, 1);
+                r = ((B0 & ~B1 & E1) | (~B0 & B1 & E2) | (B0 & B1 & E3)) & dst;
+            }
+            bits[2 * k + h] = r;
+        }
+    }
+    const u32 ooff = (u32)(x * H * D + z0);
+#pragma unroll 1
+    for (int gq = 0; gq < 4; ++gq) {                    // 8 planes at a time: byte c of G[i] = planes 8 gq .. 8 gq + 7 of cell 4 i + c
+        if (8 * gq >= np) break;
+        u32 G[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 a = (bits[4 * i] >> (8 * gq)) & 0xffu, b = (bits[4 * i + 1] >> (8 * gq)) & 0xffu, c = (bits[4 * i + 2] >> (8 * gq)) & 0xffu,
+                      d = (bits[4 * i + 3] >> (8 * gq)) & 0xffu;
+            G[i] = a | (b << 8) | (c << 16) | (d << 24);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const i64 y = y0 + 8 * gq + q;
+            if (8 * gq + q >= np) break;
+            u32 oc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) oc[i] = (G[i] >> q) & 0x01010101u;
+            if (!RGBOUT) {
+                u32x4 r; r.x = oc[0]; r.y = oc[1]; r.z = oc[2]; r.w = oc[3];
+                *(u32x4*)(out + y * D + ooff) = r;
+            } else {
+                const u8* px = rgb_hw3 + (y * W + x) * 3;
+                const u32 R = px[0], Gc = px[1], B = px[2];
+                const u32 C0 = R | (Gc << 8) | (B << 16) | (R << 24), C1 = Gc | (B << 8) | (R << 16) | (Gc << 24), C2 = B | (R << 8) | (Gc << 16) | (B << 24);
+                u32 w[12];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rgb_of_occ4(oc[i], C0, C1, C2, w + 3 * i);
+                u32x4* op = (u32x4*)(out + 3 * (y * D + (i64)ooff));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { u32x4 r; r.x = w[4 * k]; r.y = w[4 * k + 1]; r.z = w[4 * k + 2]; r.w = w[4 * k + 3]; op[k] = r; }
+            }
+        }
+    }
 }
 
 bool is_zero(double v) { return v == 0.0; }
@@ -1389,7 +1467,8 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
     const int pin = ctx->tune_rotate_tile;
     const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
     const bool packed_ok = D % 16 == 0 && W * H * D < (1ll << 32) - 64 && H >= 8;
-    const bool packed = packed_ok && (pin ? pin == 256 : (W >= 512 && D >= 512 && ptiles * ((H + 15) / 16) >= (i64)ctx->cus * 4));
+    // measured (tools/m4bench.py, 45 degrees): 512^3 0.061 ms against 0.113 (64-tiles) / 0.139 (128-tiles); 512 x 278 x 512 0.053 / 0.070 / 0.125
+    const bool packed = packed_ok && (pin ? pin == 256 : (W >= 256 && D >= 256 && ptiles * ((H + 7) / 8) >= 64));
     const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
     const bool wide = !packed && (pin ? pin == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2));
     // The step tables (cells, tile footprints, run records) depend on (matrix, offset, W, H, D) only.  A caller that repeats a step --
@@ -1405,7 +1484,7 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
     rc.kind = 0;                                        // invalid until this call has queued everything
     if (!cached) {
         if (packed) PB3D_HIP(hipMemsetAsync(lutmap, 0, 512 * sizeof(u32), ctx->stream));
-        hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)lutmap);
+        hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)lutmap);
         PB3D_CHECK_LAUNCH();
     }
     auto remember = [&]() {
@@ -1415,10 +1494,8 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
     };
     if (packed) {
         if (!ctx->packed_lds_set) {
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLdsPair));
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLdsPair));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
             ctx->packed_lds_set = true;
         }
         const int ntz = (int)((D + PT - 1) / PT);
@@ -1434,23 +1511,15 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
                                ntz, (RunRec*)runs);
             PB3D_CHECK_LAUNCH();
         }
-        const bool pair = ctx->tune_misc[3] != 1 && H >= 16;                        // misc3 = 1: the two-workgroups-per-CU form
-        int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : (pair ? 64 : 32);     // planes per workgroup (multiple of 8)
-        while (TYP > (pair ? 16 : 8) && ptiles * ((H + TYP - 1) / TYP) < (i64)ctx->cus * (pair ? 2 : 4)) TYP >>= 1;
+        // planes per workgroup: 8 = one pass (measured at 1024^3, 45 degrees, warm tables: 8 planes 0.46 ms, 16 / 32 planes 0.50 --
+        // the more workgroups, the better their stage and evaluate phases interleave across the chip)
+        int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : 8;
         const int nchunks = (int)((H + TYP - 1) / TYP);
         const i64 nblk = 8 * ptiles * ((nchunks + 7) / 8);
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
-        // walk phase of the lanes of a row group: 1/16ths of a cell per x-row along the output direction that keeps the source row
-        // (dz/dx = -m00/m02 = cot(angle)); tune misc1 overrides (development), misc1 = -1 switches the skew off
-        int skew16 = 0;
-        if (p.m02 != 0.0) { const double ct = -p.m00 / p.m02 * 16.0; skew16 = (int)nearbyint(ct < -4096.0 ? -4096.0 : (ct > 4096.0 ? 4096.0 : ct)); }
-        if (ctx->tune_misc[1] > 0) skew16 = ctx->tune_misc[1];
-        if (ctx->tune_misc[1] < 0) skew16 = 0;
-        skew16 &= 255;                                       // only the phase modulo 16 cells matters
-        auto kern = pair ? (d_mask_src ? k_rotate_bits8p<true, true> : k_rotate_bits8p<false, true>)
-                         : (d_mask_src ? k_rotate_bits8p<true, false> : k_rotate_bits8p<false, false>);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(pair ? 2 * PTHREADS : PTHREADS), pair ? kPLdsPair : kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)runs,
-                           (const PTile*)tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0], skew16);
+        auto kern = d_mask_src ? k_rotate_bits8p<true> : k_rotate_bits8p<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)runs,
+                           (const PTile*)tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0]);
         PB3D_CHECK_LAUNCH();
         remember();
         return PB3D_OK;
@@ -1485,6 +1554,30 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
     }
     PB3D_CHECK_LAUNCH();
     remember();
+    return PB3D_OK;
+}
+
+// global_carve's first rotation step (generic angle) from the mask alone; rgb != NULL: the step is also the last one and writes colours.
+// PB3D_EUNSUPPORTED (no message) when the shape does not suit the kernel: the caller runs the composed pipeline.
+int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3], const u8* d_mask_wh, const u8* d_rgb_hw3,
+                           u8* d_out) {
+    if (D % 16 != 0 || W > 16384 || W * H * D >= (1ll << 32) - 64 || (((uintptr_t)d_out) & 15u)) return PB3D_EUNSUPPORTED;
+    if (!(is_zero(M[3]) && M[4] == 1.0 && is_zero(M[5]) && is_zero(M[1]) && is_zero(M[7]) && is_zero(off[1]))) return PB3D_EUNSUPPORTED;
+    RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    void* cells;
+    PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
+    ctx->rot_cache.kind = 0;                            // slot 16 is about to hold another step's cells
+    hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)nullptr);
+    PB3D_CHECK_LAUNCH();
+    dim3 grid((unsigned)((W * (D / 16) + 255) / 256), (unsigned)((H + 31) / 32));
+    PB3D_REQUIRE(grid.y <= 65535u, "pb3d_global_carve: grid too large");
+    void* pbits;
+    PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)(W * ((H + 31) / 32)) * sizeof(u32), &pbits));
+    hipLaunchKernelGGL(k_mask_planebits, dim3(pb3d_stream_blocks(ctx, W * ((H + 31) / 32), 256, 8)), dim3(256), 0, ctx->stream, d_mask_wh, W, H, (u32*)pbits);
+    PB3D_CHECK_LAUNCH();
+    if (d_rgb_hw3) hipLaunchKernelGGL(k_first_step<true>, grid, dim3(256), (size_t)W * 4, ctx->stream, (const CellRec*)cells, (const u32*)pbits, d_rgb_hw3, W, H, D, d_out);
+    else hipLaunchKernelGGL(k_first_step<false>, grid, dim3(256), (size_t)W * 4, ctx->stream, (const CellRec*)cells, (const u32*)pbits, d_rgb_hw3, W, H, D, d_out);
+    PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
 

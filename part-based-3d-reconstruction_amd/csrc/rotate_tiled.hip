@@ -265,10 +265,19 @@ __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_
 // transpose) is 0.455 ms, a linear copy with the same workgroup shape 0.41 ms.
 // RAGGED = false: D % 16 == 0 and c2 % 16 == 0, every piece is whole and the byte-wise paths are compiled out (they cost
 // 25 % at 1024^3 when merely present)
-template <int DEPTH, bool RAGGED>
+// RGBOUT (with RAGGED = false): the step is the LAST one of a global_carve chain (reference utils/voxel_carving_utils.py:279-292) --
+// instead of the 0/1 occupancy byte, voxel (x,y,z) gets the colour rgb_hw3[y, x] where the byte is 1 (apply_colored_mask_to_voxel_grid
+// :128-136 folded into the store: 48 bytes per 16 voxels, no occupancy volume written or re-read).
+// ALIGNZ (with RAGGED): rows that are not multiples of 128 bytes, on grids with H * D % 128 == 0 -- every real shape of the reference
+// whose LONGER mask side is the height (max_dim = 128 / 256 / 512 makes H a multiple of 128; Charminar 355 x 512 x 355).  All rows
+// (x, y) of one plane then start at the same phase phi(y) = (address of row (0, y)) mod 128, so the tile grid of plane y is shifted
+// by -phi(y) along z: in the shifted coordinate z' = z + phi(y) every output piece is an ALIGNED 16 bytes and every 8-lane row
+// segment a whole 128-byte line (unshifted, each segment straddles two lines and every line is written twice, by two workgroups).
+// Only c0 (source row = c0 + phi - z'), the validity window and the two clipped pieces at a row's ends depend on the plane.
+template <int DEPTH, bool RAGGED, bool RGBOUT = false, bool ALIGNZ = false>
 __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
-                                               i64 W, i64 H, i64 D, int TY, TileMap tm) {
+                                               i64 W, i64 H, i64 D, int TY, TileMap tm, const u8* __restrict__ rgb_hw3 = nullptr) {
     __shared__ __attribute__((aligned(16))) u8 tiles[2][128 * 128];
     const int tid = threadIdx.x;
     i64 zt, xt, yc;
@@ -276,22 +285,30 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
     const i64 x0 = xt * 128, z0 = zt * 128;
     const i64 y_beg = yc * TY;
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    // phase of plane y's rows (ALIGNZ): the same for every x because H * D % 128 == 0
+    auto phi = [&](i64 y) -> i64 { return ALIGNZ ? (i64)(((uintptr_t)out + (uintptr_t)(y * D)) & 127u) : 0; };
     // staging role: local source row lr = (tid >> 3) + 32 j, 16-byte block cb = tid & 7
     const int cb = tid & 7;
-    const i64 rbase = (i64)c0 - (z0 + 127);             // source row of local row 0
+    const i64 rbase0 = (i64)c0 - (z0 + 127);            // source row of local row 0 (+ phi(y) under ALIGNZ)
     const i64 scol = x0 + c2 + 16 * cb;                 // source column of this thread's block
     const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
     // output role: z-run zg = tid & 7 (16 z), x-group xg = tid >> 3 (4 x)
     const int zg = tid & 7, xg = tid >> 3;
     const int g = 7 - zg;                               // row group holding this thread's 16 source rows
     const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
-    const i64 zo = z0 + 16 * zg;
+    const i64 zo = z0 + 16 * zg;                          // z' of this thread's run; z = zo - phi(y)
+    // 16 validity bits of row x for z = zlo .. zlo + 15 (zero outside [0, D): the table is zero there, negative z are shifted out)
+    auto vwin = [&](i64 x, i64 zlo) -> u32 {
+        if (x >= W || zlo <= -16 || zlo >= D) return 0u;
+        const i64 zs = zlo < 0 ? 0 : zlo;
+        const u32* vr = vbits + x * nw + (zs >> 5);
+        u32 v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zs & 31)) & 0xffffu;
+        if (zlo < 0) v = (v << (int)(-zlo)) & 0xffffu;
+        return v;
+    };
     u32 vb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const i64 x = x0 + 4 * xg + i;
-        vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
-    }
+    for (int i = 0; i < 4; ++i) vb[i] = ALIGNZ ? 0xffffu : vwin(x0 + 4 * xg + i, zo);
     // Everything a plane needs from global memory is issued together, DEPTH planes ahead: the 16-byte source pieces, the
     // source-row mask bytes (applied when the data lands, so the two loads are not dependent) and the
     // destination-row mask bytes.
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
     u32 msk[DEPTH];    // bit j: source-row mask of piece j ; bits 4..7: destination-row mask of row i
     auto load_plane = [&](u32x4 (&sg)[4], u32& mkout, i64 y) {
         u32 mk = 0;
+        const i64 rbase = rbase0 + phi(y);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
@@ -356,23 +374,54 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 o[2][w] = perm(u1, t1, 0x05040100u);
                 o[3][w] = perm(u1, t1, 0x07060302u);
             }
+            const i64 ph = phi(y), zlo = zo - ph;                     // this run's true z range is zlo .. zlo + 15
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const i64 x = x0 + 4 * xg + i;
-                if (x >= W || zo >= D) continue;
+                if (x >= W || zlo >= D || (ALIGNZ && zlo <= -16)) continue;
+                const u32 vbi = ALIGNZ ? vwin(x, zlo) : vb[i];
                 u32x4 r = (u32x4)(0u);
                 if ((mkc >> (4 + i)) & 1u) {
                     r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
-                    if (vb[i] != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
+                    if (vbi != 0xffffu) {  // border cells rejected by the f64 bounds test (rare) -- and, under ALIGNZ, bytes outside the row
                         u32 mw[4];
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
-                            const u32 b4 = (vb[i] >> (4 * w)) & 0xfu;
+                            const u32 b4 = (vbi >> (4 * w)) & 0xfu;
                             mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) |
                                     ((b4 & 8u) ? 0xff000000u : 0u);
                         }
                         r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
                     }
+                }
+                if (RGBOUT) {
+                    const u8* px = rgb_hw3 + (y * W + x) * 3;
+                    const u32 R = px[0], G = px[1], B = px[2];
+                    const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
+                    const u32 oc[4] = {r.x, r.y, r.z, r.w};
+                    u32 w[12];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // carved == 1 (the chain only ever holds 0 / 1): bytes 0x00 / 0xff, spread over the voxel's three colour bytes
+                        u32 e = oc[q] ^ 0x01010101u;                                   // 0 where the byte is 1
+                        e = ~(((e & 0x7f7f7f7fu) + 0x7f7f7f7fu) | e) & 0x80808080u;   // 0x80 where that byte is zero
+                        e = (e >> 7) * 0xffu;
+                        w[3 * q] = perm(e, e, 0x01000000u) & C0; w[3 * q + 1] = perm(e, e, 0x02020101u) & C1; w[3 * q + 2] = perm(e, e, 0x03030302u) & C2;
+                    }
+                    u32x4* op3 = (u32x4*)(out + 3 * ((x * H + y) * D + zo));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { u32x4 v; v.x = w[4 * k]; v.y = w[4 * k + 1]; v.z = w[4 * k + 2]; v.w = w[4 * k + 3]; op3[k] = v; }   // plain stores: a lane's three pieces interleave with its neighbours' in every line; the L2 merges them (nontemporal: 2.1 ms)
+                    continue;
+                }
+                if (ALIGNZ) {
+                    u8* opa = out + (x * H + y) * D + zlo;                 // 16-byte aligned by construction
+                    if (zlo >= 0 && zlo + 15 < D) __builtin_nontemporal_store(r, (u32x4*)opa);
+                    else {                                                 // one of the two clipped pieces of the row: its own bytes only
+                        const u32 t4[4] = {r.x, r.y, r.z, r.w};
+                        for (int b = 0; b < 16; ++b)
+                            if (zlo + b >= 0 && zlo + b < D) opa[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+                    }
+                    continue;
                 }
                 u8* op = out + (x * H + y) * D + zo;
                 if (!RAGGED || zo + 15 < D) __builtin_nontemporal_store(r, (u32x4_u*)op);
@@ -643,22 +692,33 @@ static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u3
 }
 
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
-                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out) {
+                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out, const u8* d_rgb_hw3) {
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     const PermMap pm = perm_map(M, off);
     const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
     PB3D_REQUIRE(rot90 || (D % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 3u) == 0), "pb3d_rotate_perm: needs D %% 4 == 0");
+    PB3D_REQUIRE(!d_rgb_hw3 || (rot90 && W <= 65535 * 128 && H <= 65535), "pb3d_rotate_perm: colour output is a 90-degree step");
     if (rot90 && W <= 65535 * 128 && H <= 65535) {
         u32* bits; int nw;
         PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-        const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
+        // rows that are not whole lines, but all rows of a plane at one phase: the plane-shifted tile grid (k_rot90<.., ALIGNZ>)
+        const bool alignz = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
+        const i64 nzt = alignz ? (D + 127 + 127) / 128 : (D + 127) / 128;
+        const i64 tiles = nzt * ((W + 127) / 128);
         const int TY = planes_per_chunk(H, tiles, ctx->cus, 32);
-        const TileMap tm = {(int)((D + 127) / 128), (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2]};
+        const TileMap tm = {(int)nzt, (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2] == 1 ? 1 : 0};
         dim3 grid(tilemap_blocks(tm));
 #ifndef PB3D_ROT90_DEPTH
 #define PB3D_ROT90_DEPTH 1
 #endif
-        if (D % 16 == 0 && pm.c2 % 16 == 0)
+        if (d_rgb_hw3) {
+            PB3D_REQUIRE(D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_out) & 15u) == 0, "pb3d_rotate_perm: colour output needs D %% 16 == 0");
+            hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm, d_rgb_hw3);
+        } else if (alignz)
+            hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, true, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
+        else if (D % 16 == 0 && pm.c2 % 16 == 0)
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
         else

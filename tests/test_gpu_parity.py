@@ -305,7 +305,9 @@ def test_process90_tiled_permutation_sizes(pb3d_gpu, oracle):
     for (W, H, D) in [(100, 7, 100), (68, 5, 132), (132, 3, 68), (64, 2, 64), (4, 3, 4), (260, 4, 260), (200, 2, 72),
                       (130, 3, 62), (63, 4, 64), (65, 2, 65), (128, 3, 128), (256, 2, 256), (192, 5, 192),
                       (355, 6, 355), (123, 9, 123), (37, 5, 51), (51, 5, 37), (131, 7, 129), (1, 3, 1), (17, 4, 1), (1, 4, 17),
-                      (150, 3, 200), (437, 2, 437), (15, 11, 15), (16, 3, 18)]:
+                      (150, 3, 200), (437, 2, 437), (15, 11, 15), (16, 3, 18),
+                      # H * D % 128 == 0 with rows that are not whole lines: the plane-shifted tile grid (k_rot90<ALIGNZ>)
+                      (355, 128, 355), (131, 256, 131), (136, 128, 200), (200, 128, 136), (129, 384, 129), (437, 128, 437)]:
         for kind in ("bin", "full"):
             g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "bin" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
             m = rng.random((H, W)) < 0.85
@@ -1128,3 +1130,28 @@ def test_full_size_connected_components_1024(pb3d_gpu, oracle):
         for v in range(S):
             sums += np.bincount(moved[v].ravel(), minlength=n + 1) * v
         assert np.array_equal(np.array(csum[:3 * n]).reshape(n, 3)[:, axis], sums[1:]), axis
+
+
+@pytest.mark.gpu
+def test_global_carve_fused_chain_other_angles(pb3d_gpu, oracle, golden):
+    """global_carve with angle steps other than 90: the fused chain (first step synthesised from the mask, colours written by the last
+    step) and the composed pipeline (ones -> process_voxel_grid -> colour apply, tune misc3 = 1) both equal the oracle -- widths that
+    suit the fused kernels (w % 16 == 0) and widths that fall back, one / two / three rotation steps, and the reference fixtures."""
+    rng = np.random.default_rng(123)
+    pal = np.array(list(pb3d_gpu.PART_COLORS.values()), np.uint8)
+    for (h, w) in ((40, 64), (33, 48), (20, 128), (31, 50), (17, 37), (64, 160)):
+        lab = rng.integers(0, len(pal), (h // 4 + 1, w // 4 + 1)).repeat(4, 0).repeat(4, 1)[:h, :w]
+        sem = pal[lab]
+        binary = (rng.random((h, w)) < 0.85) & (lab != len(pal) - 1)
+        for ai in (45, 60, 30, 50, 89):
+            want = oracle.global_carve(binary, sem, ai)
+            for composed in (0, 1):
+                pb3d_gpu._lib.set_tuning("misc3", composed)
+                try:
+                    got = pb3d_gpu.global_carve(binary, sem, ai)
+                finally:
+                    pb3d_gpu._lib.set_tuning("misc3", 0)
+                assert np.array_equal(got, want), (h, w, ai, composed, int((got != want).sum()))
+    for name in ("f4_Akbar_64", "f4_Bibi_64", "f4_Taj_96"):
+        g = golden(name)
+        assert np.array_equal(pb3d_gpu.global_carve(g["binary"], g["ext"], 45), g["global_carve_45"]), name

@@ -25,6 +25,19 @@ for mon in ("Akbar", "Charminar"):
     for _ in range(n):
         obj(prm)
     dt = (time.perf_counter() - t0) / n
-    print(json.dumps({"monument": mon, "points": int(len(pts)), "image": [m["H"], m["W"]], "parts": len(m["parts"]),
-                      "us_per_evaluation": round(dt * 1e6, 1), "evaluations_per_s": round(1 / dt)}), flush=True)
+    # K cameras per launch (pb3d_project_iou_batch_dev): perturbations of the same camera, as the random / coordinate stages make them
+    rng = np.random.default_rng(1)
+    rec = {"monument": mon, "points": int(len(pts)), "image": [m["H"], m["W"]], "parts": len(m["parts"]),
+           "us_per_evaluation_one_at_a_time": round(dt * 1e6, 1)}
+    for K in (16, 64, 256, 1024):
+        batch = [dict(prm, cam_pos=prm["cam_pos"] + rng.normal(size=3), target=prm["target"] + rng.normal(size=3) * 0.3,
+                      f=prm["f"] * (1 + 0.01 * rng.normal())) for _ in range(K)]
+        got = obj.evaluate_batch(batch)
+        assert got[:4] == [obj(p) for p in batch[:4]]
+        reps = max(2, 2048 // K)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            obj.evaluate_batch(batch)
+        rec[f"us_per_camera_batch_{K}"] = round((time.perf_counter() - t0) / reps / K * 1e6, 2)
+    print(json.dumps(rec), flush=True)
     obj.close()
