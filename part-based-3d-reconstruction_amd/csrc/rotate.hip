@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const i64 x = x0 + 32 * k + (tid >> 4), z = z0 + zc;
-        run[k] = (u32x4)(0u, 0u, 0xffffffffu, 0xffffffffu);
+        run[k] = u32x4{0u, 0u, 0xffffffffu, 0xffffffffu};          // outside the grid: 16 void cells at the footprint origin
         if (x < W && z < D) run[k] = *(const u32x4*)(runs + x * (D / 16) + (z >> 4));
     }
     __syncthreads();

@@ -406,6 +406,36 @@ def test_connected_components_device(pb3d_gpu, golden, oracle):
         b.free()
 
 
+@pytest.mark.gpu
+def test_connected_components_row_frame_shapes(pb3d_gpu, oracle):
+    """The labelling works on 64-voxel windows of rows cut from a flat bit stream: rows shorter than, equal to and longer than a
+    window, odd lengths (windows that straddle dwords of the stream), runs that cross windows, densities from salt noise to nearly
+    full, plus the degenerate axes -- every label volume equals the oracle's scipy numbering."""
+    from pb3d import device as dev
+    from pb3d.voxel_carving_utils import _component_stats, _label
+    rng = np.random.default_rng(77)
+    col = np.array((200, 10, 30), np.uint8)
+    shapes = [(1, 1, 1), (1, 1, 70), (3, 1, 64), (5, 7, 1), (4, 5, 63), (4, 5, 65), (6, 3, 128), (7, 9, 129), (9, 8, 191), (12, 10, 200),
+              (33, 17, 355), (16, 16, 16), (2, 40, 31), (40, 2, 97), (21, 22, 23)]
+    for shp in shapes:
+        for dens in (0.05, 0.5, 0.9, 1.0):
+            mask = rng.random(shp) < dens
+            if dens == 0.9:                                     # long runs with a few cuts: runs cross windows, few unions per row
+                mask = np.ones(shp, bool); mask[rng.random(shp) < 0.02] = False
+            grid = rng.integers(0, 3, shp + (3,)).astype(np.uint8)          # other colours around the members
+            grid[mask] = col
+            mask = np.all(grid == col, axis=-1)
+            d_g = dev.from_numpy(grid); d_lab = dev.DeviceBuffer(mask.size * 4)
+            n = _label(d_g, shp, col, d_lab)
+            want, nw = oracle.label6(mask)
+            got = d_lab.download(shp, np.int32)
+            assert n == nw and np.array_equal(got, want), (shp, dens)
+            if n:
+                bbox, cnt, sums = _component_stats(d_lab, shp, n)
+                assert np.array_equal(cnt, np.bincount(want.ravel(), minlength=n + 1)[1:]), (shp, dens)
+            d_g.free(); d_lab.free()
+
+
 @pytest.mark.parametrize("name", ["Taj_96", "Akbar_64", "Bibi_80"])
 def test_partwise_stages_f5(pb3d_gpu, golden, name):
     """N1/N2: component-guided carve (incl. its printed log), extrusion, recolouring and the whole partwise_carve
