@@ -152,11 +152,16 @@ __device__ __forceinline__ bool tile_of_block(const TileMap m, i64* zt, i64* xt,
     return *yc < m.nyc;
 }
 // planes per workgroup such that the plane chunks spread evenly over the 8 XCDs (a multiple of 8 chunks where possible) and the
-// grid still fills the chip
-static inline int planes_per_chunk(i64 H, i64 tiles, int cus, int want_ty) {
+// launch has `fill` workgroups per CU -- two rounds of the 4 that are resident.  Measured with tools/tybench.py (variants interleaved
+// on one box, process_voxel_grid(occ, 90), ms): fill 4 / 6 / 8 / 12 = 0.460 / 0.462 / 0.460 / 0.473 at 1024^3, 0.083 / 0.093 / 0.0735 /
+// 0.082 at 512^3, 0.122 / 0.121 / 0.101 / 0.104 at 437x512x437, 0.093 / 0.082 / 0.080 / 0.072 at 355x512x355; a model of whole
+// "rounds" of workgroups did not predict these (exactly one round is never the best: nothing is left to fill the slots of the
+// workgroups that finish early).
+static inline int planes_per_chunk(i64 H, i64 tiles, int cus, int want_ty, int fill = 0) {
+    if (fill <= 0) fill = 8;
     i64 m = (H + 8 * want_ty - 1) / (8 * want_ty);                 // chunks = 8 m
     if (m < 1) m = 1;
-    while (tiles * 8 * m < (i64)cus * 6 && 8 * (m + 1) <= H) ++m;
+    while (tiles * 8 * m < (i64)cus * fill && 8 * (m + 1) <= H) ++m;
     i64 ty = (H + 8 * m - 1) / (8 * m);
     return (int)(ty < 1 ? 1 : ty);
 }
@@ -314,9 +319,14 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
     // destination-row mask bytes.
     u32x4 stg[DEPTH][4];
     u32 msk[DEPTH];    // bit j: source-row mask of piece j ; bits 4..7: destination-row mask of row i
-    auto load_plane = [&](u32x4 (&sg)[4], u32& mkout, i64 y) {
+    u32 vbn[DEPTH][ALIGNZ ? 4 : 1];   // ALIGNZ: the plane's own validity windows (z = zo - phi(y)), fetched with the plane's data
+    auto load_plane = [&](u32x4 (&sg)[4], u32& mkout, u32 (&vn)[ALIGNZ ? 4 : 1], i64 y) {
         u32 mk = 0;
         const i64 rbase = rbase0 + phi(y);
+        if (ALIGNZ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vn[i] = y < y_end ? vwin(x0 + 4 * xg + i, zo - phi(y)) : 0u;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
@@ -338,12 +348,12 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const i64 x = x0 + 4 * xg + i;
-            if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
+            if (y < y_end && x < W && (ALIGNZ ? vn[i] : vb[i])) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
         }
         mkout = mk;
     };
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) load_plane(stg[s], msk[s], y_beg + s);
+    for (int s = 0; s < DEPTH; ++s) load_plane(stg[s], msk[s], vbn[s], y_beg + s);
     int buf = 0;
     for (i64 y0p = y_beg; y0p < y_end; y0p += DEPTH) {
 #pragma unroll
@@ -359,7 +369,10 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ((mkc >> j) & 1u) ? stg[s][j] : (u32x4)(0u);
             }
             __syncthreads();      // the only barrier of the plane: the other tile buffer was last read before the previous one
-            load_plane(stg[s], msk[s], y + DEPTH);
+            u32 vcur[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vcur[i] = ALIGNZ ? vbn[s][i] : vb[i];
+            load_plane(stg[s], msk[s], vbn[s], y + DEPTH);
             u32 d[16];
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
             for (int i = 0; i < 4; ++i) {
                 const i64 x = x0 + 4 * xg + i;
                 if (x >= W || zlo >= D || (ALIGNZ && zlo <= -16)) continue;
-                const u32 vbi = ALIGNZ ? vwin(x, zlo) : vb[i];
+                const u32 vbi = vcur[i];
                 u32x4 r = (u32x4)(0u);
                 if ((mkc >> (4 + i)) & 1u) {
                     r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
@@ -416,10 +429,18 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 if (ALIGNZ) {
                     u8* opa = out + (x * H + y) * D + zlo;                 // 16-byte aligned by construction
                     if (zlo >= 0 && zlo + 15 < D) __builtin_nontemporal_store(r, (u32x4*)opa);
-                    else {                                                 // one of the two clipped pieces of the row: its own bytes only
-                        const u32 t4[4] = {r.x, r.y, r.z, r.w};
-                        for (int b = 0; b < 16; ++b)
-                            if (zlo + b >= 0 && zlo + b < D) opa[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+                    else {                                                 // one of the two clipped pieces of the row: its own bytes only --
+                        const u32 t4[4] = {r.x, r.y, r.z, r.w};            // whole dwords inside the row as dwords, the rest byte by byte
+                        const int b0 = zlo < 0 ? (int)-zlo : 0, b1 = zlo + 16 > D ? (int)(D - zlo) : 16;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            if (4 * w >= b0 && 4 * w + 4 <= b1) *(u32*)(opa + 4 * w) = t4[w];
+                            else if (4 * w + 4 > b0 && 4 * w < b1) {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b)
+                                    if (4 * w + b >= b0 && 4 * w + b < b1) opa[4 * w + b] = (u8)(t4[w] >> (8 * b));
+                            }
+                        }
                     }
                     continue;
                 }
@@ -432,6 +453,144 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                     for (int b = k & ~3; b < k; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2' for rows that are not whole lines, FLAT form (grids with H * D % 128 == 0: every real shape of the reference whose longer mask
+// side is the height, e.g. Charminar 355 x 512 x 355).  For a fixed x the rows (x, y, :) of all planes follow each other in memory:
+// an output x-row is ONE contiguous stream of H * D bytes, f = y * D + z.  The kernel tiles that stream, not the planes: a tile is
+// 128 x-rows x one aligned 128-byte SEGMENT s of the stream (f = 128 s .. 128 s + 127), whatever rows of whichever one or two planes
+// it holds.  Every store is then a whole aligned line, nothing is clipped at row ends, and a launch has H * D / 128 segment steps per
+// x-tile instead of ceil((D + 127) / 128) * H tile-planes (355 x 512 x 355: 1420 against 2048).  Byte j of segment s is voxel
+// (y, z) = divmod(128 s + j, D) and comes from source row n0 = c0 - z of plane y: 128 row reads of 128 bytes along x, as in k_rot90;
+// LDS layout, transpose and thread roles are k_rot90's (local source row lr holds byte j = 127 - lr).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90_flat(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
+                                                                 const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
+                                                                 i64 W, i64 H, i64 D, int TS, TileMap tm, pb3d_magic mD, i64 nseg) {
+    __shared__ __attribute__((aligned(16))) u8 tiles[2][128 * 128];
+    const int tid = threadIdx.x;
+    i64 zt, xt, sc;
+    if (!tile_of_block(tm, &zt, &xt, &sc)) return;                          // whole workgroup, before any barrier
+    const i64 x0 = xt * 128;
+    const i64 s_beg = sc * TS;
+    const i64 s_end = s_beg + TS < nseg ? s_beg + TS : nseg;
+    const i64 HD = H * D;
+    const int cb = tid & 7;
+    const i64 scol = x0 + c2 + 16 * cb;                 // source column of this thread's block
+    const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
+    const int zg = tid & 7, xg = tid >> 3;
+    const int g = 7 - zg;
+    const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
+    // 16 validity bits of row x for z = zlo .. zlo + 15 (zero outside [0, D))
+    auto vwin = [&](i64 x, i64 zlo) -> u32 {
+        if (zlo <= -16 || zlo >= D) return 0u;
+        const i64 zs = zlo < 0 ? 0 : zlo;
+        const u32* vr = vbits + x * nw + (zs >> 5);
+        u32 v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zs & 31)) & 0xffffu;
+        if (zlo < 0) v = (v << (int)(-zlo)) & 0xffffu;
+        return v;
+    };
+    u32x4 stg[4];
+    u32 msk;           // bit j: source-row mask of piece j
+    u32 keep[4];       // per output row: the 16 keep bits of this thread's piece (validity AND destination-row mask)
+    auto load_seg = [&](i64 s) {
+        u32 mk = 0;
+        const bool live = s < s_end;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 3) + 32 * j;
+            const u32 f = (u32)(128 * s) + (u32)(127 - lr);
+            const u32 y = pb3d_div(f, mD), z = f - y * mD.d;
+            const i64 n0 = (i64)c0 - (i64)z;
+            stg[j] = (u32x4)(0u);
+            if (live && cmode != 0 && n0 >= 0 && n0 < W) {
+                const u8* sp = in + (n0 * H + (i64)y) * D + scol;
+                // a ragged piece may be read whole as long as it stays inside the volume: the bytes beyond the row belong to
+                // the neighbouring row and are dropped by the validity bits (their source column is outside [0, D))
+                if (cmode == 2 || (sp >= in && sp + 16 <= in + W * HD)) stg[j] = __builtin_nontemporal_load((const u32x4_u*)sp);
+                else {
+                    u32 t4[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; ++b)
+                        if (scol + b >= 0 && scol + b < D) t4[b >> 2] |= (u32)sp[b] << (8 * (b & 3));
+                    stg[j].x = t4[0]; stg[j].y = t4[1]; stg[j].z = t4[2]; stg[j].w = t4[3];
+                }
+                mk |= (u32)((mask_src ? mask_src[n0 * H + (i64)y] : (u8)1) != 0) << j;
+            }
+        }
+        msk = mk;
+        // this thread's output piece: bytes j = 16 zg .. 16 zg + 15 of the segment = voxels (y, z .. ) and, past a row end, (y + 1, 0 ..)
+        const u32 f = (u32)(128 * s) + (u32)(16 * zg);
+        const u32 y = live ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+        const int nA = (i64)z + 16 <= D ? 16 : (int)(D - (i64)z);          // bytes of the piece in plane y (D >= 16)
+        const u32 lowA = (1u << nA) - 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            u32 k = 0;
+            if (live && x < W) {
+                u32 bits = vwin(x, (i64)z);
+                if (nA < 16) bits |= vwin(x, (i64)z - D);
+                if (bits) {
+                    const u32 mA = (mask_dst ? mask_dst[x * H + (i64)y] : (u8)1) != 0 ? lowA : 0u;
+                    const u32 mB = (nA < 16 && (mask_dst ? mask_dst[x * H + (i64)y + 1] : (u8)1) != 0) ? (0xffffu & ~lowA) : 0u;
+                    k = bits & (mA | mB);
+                }
+            }
+            keep[i] = k;
+        }
+    };
+    load_seg(s_beg);
+    int buf = 0;
+    for (i64 s = s_beg; s < s_end; ++s) {
+        u8* tile = tiles[buf];
+        buf ^= 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 3) + 32 * j;
+            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ((msk >> j) & 1u) ? stg[j] : (u32x4)(0u);
+        }
+        __syncthreads();      // the only barrier of the segment: the other tile buffer was last read before the previous one
+        u32 kcur[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kcur[i] = keep[i];
+        load_seg(s + 1);
+        u32 d[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
+        u32 o[4][4];  // o[i][w]: output x = 4 xg + i, bytes q = 4w .. 4w+3 ; byte q <- d[15 - q].byte[i]
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 A = d[15 - 4 * w], B = d[14 - 4 * w], Cc = d[13 - 4 * w], E = d[12 - 4 * w];
+            const u32 t0 = perm(B, A, 0x05010400u), t1 = perm(B, A, 0x07030602u);
+            const u32 u0 = perm(E, Cc, 0x05010400u), u1 = perm(E, Cc, 0x07030602u);
+            o[0][w] = perm(u0, t0, 0x05040100u);
+            o[1][w] = perm(u0, t0, 0x07060302u);
+            o[2][w] = perm(u1, t1, 0x05040100u);
+            o[3][w] = perm(u1, t1, 0x07060302u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            if (x >= W) continue;
+            const u32 kb = kcur[i];
+            u32x4 r = (u32x4)(0u);
+            if (kb) {
+                r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
+                if (kb != 0xffffu) {
+                    u32 mw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 b4 = (kb >> (4 * w)) & 0xfu;
+                        mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) |
+                                ((b4 & 8u) ? 0xff000000u : 0u);
+                    }
+                    r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
+                }
+            }
+            __builtin_nontemporal_store(r, (u32x4*)(out + x * HD + 128 * s + 16 * zg));     // a whole aligned piece of a whole aligned line
         }
     }
 }
@@ -702,10 +861,13 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         u32* bits; int nw;
         PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
         // rows that are not whole lines, but all rows of a plane at one phase: the plane-shifted tile grid (k_rot90<.., ALIGNZ>)
-        const bool alignz = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
+        // ... or, better, the stream of each x-row tiled in whole lines (k_rot90_flat); tune misc2: 2 = neither, 3 = the plane-shifted grid
+        const bool lines_ok = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
+        const bool flat = lines_ok && ctx->tune_misc[2] != 3 && H * D < (1ll << 31) && (((uintptr_t)d_out) & 127u) == 0;
+        const bool alignz = lines_ok && !flat;
         const i64 nzt = alignz ? (D + 127 + 127) / 128 : (D + 127) / 128;
         const i64 tiles = nzt * ((W + 127) / 128);
-        const int TY = planes_per_chunk(H, tiles, ctx->cus, 32);
+        const int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_misc[1]);
         const TileMap tm = {(int)nzt, (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2] == 1 ? 1 : 0};
         dim3 grid(tilemap_blocks(tm));
 #ifndef PB3D_ROT90_DEPTH
@@ -715,6 +877,12 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
             PB3D_REQUIRE(D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_out) & 15u) == 0, "pb3d_rotate_perm: colour output needs D %% 16 == 0");
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm, d_rgb_hw3);
+        } else if (flat) {
+            const i64 nseg = H * D / 128, nxt = (W + 127) / 128;
+            const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
+            const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
+            hipLaunchKernelGGL(k_rot90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
+                               pm.c0, pm.c2, W, H, D, TS, fm, pb3d_make_magic((u32)D), nseg);
         } else if (alignz)
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, true, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
@@ -802,7 +970,7 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     PB3D_CHECK_LAUNCH();
     if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
     const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
-    const int TY = planes_per_chunk(H, tiles, ctx->cus, 32);
+    const int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_misc[1]);
     const TileMap tm = {(int)((D + 127) / 128), (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2]};
     dim3 grid(tilemap_blocks(tm));
     auto kern = rgbsrc ? (ragged ? k_part90<true, true> : k_part90<true, false>) : (ragged ? k_part90<false, true> : k_part90<false, false>);

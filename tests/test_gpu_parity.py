@@ -306,14 +306,22 @@ def test_process90_tiled_permutation_sizes(pb3d_gpu, oracle):
                       (130, 3, 62), (63, 4, 64), (65, 2, 65), (128, 3, 128), (256, 2, 256), (192, 5, 192),
                       (355, 6, 355), (123, 9, 123), (37, 5, 51), (51, 5, 37), (131, 7, 129), (1, 3, 1), (17, 4, 1), (1, 4, 17),
                       (150, 3, 200), (437, 2, 437), (15, 11, 15), (16, 3, 18),
-                      # H * D % 128 == 0 with rows that are not whole lines: the plane-shifted tile grid (k_rot90<ALIGNZ>)
-                      (355, 128, 355), (131, 256, 131), (136, 128, 200), (200, 128, 136), (129, 384, 129), (437, 128, 437)]:
+                      # H * D % 128 == 0 with rows that are not whole lines: each x-row's stream tiled in whole lines (k_rot90_flat;
+                      # segments that straddle two planes) and, under tune misc2 = 3, the plane-shifted tile grid (k_rot90<ALIGNZ>)
+                      (355, 128, 355), (131, 256, 131), (136, 128, 200), (200, 128, 136), (129, 384, 129), (437, 128, 437),
+                      (130, 64, 130), (300, 32, 172), (141, 1024, 141)]:
+        lines = D % 128 != 0 and (H * D) % 128 == 0 and D >= 128
         for kind in ("bin", "full"):
             g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "bin" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
             m = rng.random((H, W)) < 0.85
-            got = pb3d_gpu.process_voxel_grid(g, m, 90)
             want = oracle.process_voxel_grid(g, m, 90)
-            assert np.array_equal(got, want), (W, H, D, kind, int((got != want).sum()))
+            for misc2 in ((0, 3) if lines else (0,)):
+                pb3d_gpu._lib.set_tuning("misc2", misc2)
+                try:
+                    got = pb3d_gpu.process_voxel_grid(g, m, 90)
+                finally:
+                    pb3d_gpu._lib.set_tuning("misc2", 0)
+                assert np.array_equal(got, want), (W, H, D, kind, misc2, int((got != want).sum()))
 
 
 def test_global_carve_slabs_device(pb3d_gpu, oracle):

@@ -1,0 +1,48 @@
+"""Development A/B of the planes-per-workgroup rule of the 90-degree kernels: process_voxel_grid(occ, 90) under tune misc1 = fill
+(0 = the built-in rule), variants interleaved and repeated so that clock / box drift shows up as spread instead of as a winner.
+python tools/tybench.py --shapes 1024x1024x1024,512x512x512 --fills 0,4,6,8,12 --rounds 3"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "part-based-3d-reconstruction_amd"))
+import numpy as np  # noqa: E402
+import pb3d  # noqa: E402
+from pb3d import device as dev  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn(); dev.sync()
+    e0, e1 = dev.Event(), dev.Event()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); dev.sync()
+    return e1.elapsed_ms_since(e0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="1024x1024x1024,512x512x512,437x512x437,355x512x355")
+    ap.add_argument("--fills", default="0,4,6,8,12,16")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    rng = np.random.default_rng(5)
+    for sh in a.shapes.split(","):
+        W, H, D = (int(v) for v in sh.split("x"))
+        nvox = W * H * D
+        d_mwh = dev.from_numpy((rng.random((W, H)) < 0.8).astype(np.uint8))
+        d_occ = dev.DeviceBuffer(nvox); d_o = dev.DeviceBuffer(nvox); d_t = dev.DeviceBuffer(nvox)
+        dev.synth_occ(0, W, H, D, 0, d_occ)
+        res = {}
+        for r in range(a.rounds):
+            for f in a.fills.split(","):
+                pb3d._lib.set_tuning("misc1", int(f))
+                res.setdefault(f, []).append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t), a.reps), 4))
+        pb3d._lib.set_tuning("misc1", 0)
+        print(json.dumps({"shape": [W, H, D], "ms_by_fill": res}), flush=True)
+        for b in (d_mwh, d_occ, d_o, d_t):
+            b.free()
+
+
+if __name__ == "__main__":
+    main()
