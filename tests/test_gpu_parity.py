@@ -344,10 +344,19 @@ def test_global_carve_slabs_device(pb3d_gpu, oracle):
                 parts.append(slab.download((x1 - x0, S, S, 3)))
             assert np.array_equal(np.concatenate(parts, 0), want), (S, nr)
     # widths that are not multiples of 16 go through the byte-store variant; non-square images too
-    for (h, w) in [(50, 50), (33, 70), (64, 40), (20, 144)]:
+    # ... and, when the height is a multiple of 16, through the flat form (k_global_carve90f: the rows of a y-chunk as one stream of
+    # aligned pieces, pieces that straddle two rows); tune misc2 = 2 keeps the row-wise variant
+    for (h, w) in [(50, 50), (33, 70), (64, 40), (20, 144), (32, 355), (16, 37), (16, 17), (48, 131), (128, 141), (64, 16), (80, 22)]:
         lab, binary, rgb = synth_host.mask16(max(h, w))
         binary, rgb = np.ascontiguousarray(binary[:h, :w]), np.ascontiguousarray(rgb[:h, :w])
-        assert np.array_equal(pb3d_gpu.global_carve(binary, rgb, 90), oracle.global_carve(binary, rgb, 90)), (h, w)
+        want = oracle.global_carve(binary, rgb, 90)
+        for misc2 in (0, 2):
+            pb3d_gpu._lib.set_tuning("misc2", misc2)
+            try:
+                got = pb3d_gpu.global_carve(binary, rgb, 90)
+            finally:
+                pb3d_gpu._lib.set_tuning("misc2", 0)
+            assert np.array_equal(got, want), (h, w, misc2)
 
 
 def test_deformation_loop_f8(pb3d_gpu, oracle, golden):
