@@ -247,15 +247,20 @@ __device__ __forceinline__ u32 select16_occ(const u8* __restrict__ grid, i64 v0,
     return bits;
 }
 
+// masks (one u16 per thread = per 16 voxels, n / 8 bytes in all): the fill pass takes the selection from them instead of recomputing it,
+// and loads the grid only where something is selected -- an empty 128-byte line is then read once (here), not twice.
 template <int C>
-__global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ grid, SelParams p, u32* __restrict__ block_counts) {
+__global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ grid, SelParams p, u32* __restrict__ block_counts,
+                                                        unsigned short* __restrict__ masks) {
     __shared__ u32 wsum[4];
     __shared__ u32 htab[256];
     htab[threadIdx.x] = p.htab[threadIdx.x];
     __syncthreads();
     const i64 v0 = (i64)blockIdx.x * kBlockVox + 16 * threadIdx.x;
     u32 w[12];
-    u32 c = v0 < p.nlat ? (u32)__popc(C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
+    const u32 sel = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
+    masks[(i64)blockIdx.x * 256 + threadIdx.x] = (unsigned short)sel;
+    u32 c = (u32)__popc(sel);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -285,7 +290,8 @@ constexpr int kSpinLimit = 1 << 22;   // ~ seconds: far beyond any legitimate wa
 
 template <int C, bool SINGLE>
 __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
-                                                       float* __restrict__ pts, u8* __restrict__ cols, ScanState st) {
+                                                       float* __restrict__ pts, u8* __restrict__ cols, ScanState st,
+                                                       const unsigned short* __restrict__ masks) {
     __shared__ u32 wsum[4];
     __shared__ u32 htab[256];
     __shared__ unsigned short lidx[kBlockVox];
@@ -298,7 +304,21 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     const i64 base = (i64)bid * kBlockVox;
     const i64 v0 = base + 16 * threadIdx.x;
     u32 w[12];
-    const u32 bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
+    u32 bits;
+    if (SINGLE) bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
+    else {
+        // the count pass left the selection: only the voxels' bytes (their colours) are needed, and only where something is selected
+        bits = masks[(i64)bid * 256 + threadIdx.x];
+        if (bits) {
+            if (v0 + 16 <= p.nlat) {
+                const u32x4v* g = (const u32x4v*)(grid + (C == 3 ? 3 : 1) * v0);
+#pragma unroll
+                for (int q = 0; q < (C == 3 ? 3 : 1); ++q) { const u32x4v t = g[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
+            } else {
+                (void)(C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w));   // the grid's ragged end: bounds-checked loads
+            }
+        }
+    }
     const u32 c = (u32)__popc(bits);
     u32 inc = c;
     for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
@@ -504,8 +524,10 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
     PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)nb * sizeof(u32), &counts));
     PB3D_TRY(pb3d_scratch(ctx, 9, (size_t)(nb + 1) * sizeof(i64), &offsets));
     const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
-    if (fast16 && C == 3) hipLaunchKernelGGL(k_points_count16<3>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
-    else if (fast16) hipLaunchKernelGGL(k_points_count16<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
+    void* masks = nullptr;
+    if (fast16) PB3D_TRY(pb3d_scratch(ctx, 25, (size_t)nb * 256 * sizeof(unsigned short), &masks));
+    if (fast16 && C == 3) hipLaunchKernelGGL(k_points_count16<3>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts, (unsigned short*)masks);
+    else if (fast16) hipLaunchKernelGGL(k_points_count16<1>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts, (unsigned short*)masks);
     else hipLaunchKernelGGL(k_points_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts);
     PB3D_CHECK_LAUNCH();
     i64* total = (i64*)offsets + nb;
@@ -543,12 +565,14 @@ int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64
     PB3D_REQUIRE(ctx->scratch[9] && ctx->scratch_bytes[9] >= (size_t)(nb + 1) * sizeof(i64),
                  "pb3d_points_fill: call pb3d_points_count first");
     const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
+    PB3D_REQUIRE(!fast16 || (ctx->scratch[25] && ctx->scratch_bytes[25] >= (size_t)nb * 256 * sizeof(unsigned short)),
+                 "pb3d_points_fill: call pb3d_points_count first");
     if (fast16 && C == 1)
         hipLaunchKernelGGL((k_points_fill16<1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
-                           d_cols, ScanState{});
+                           d_cols, ScanState{}, (const unsigned short*)ctx->scratch[25]);
     else if (fast16)
         hipLaunchKernelGGL((k_points_fill16<3, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
-                           d_cols, ScanState{});
+                           d_cols, ScanState{}, (const unsigned short*)ctx->scratch[25]);
     else
         hipLaunchKernelGGL(k_points_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
                            d_cols);
@@ -575,8 +599,8 @@ int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, in
     st.status = (unsigned long long*)((u8*)stv + 64);
     st.total = (i64*)((u8*)stv + 8);
     st.capacity = capacity;
-    if (C == 1) hipLaunchKernelGGL((k_points_fill16<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st);
-    else hipLaunchKernelGGL((k_points_fill16<3, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st);
+    if (C == 1) hipLaunchKernelGGL((k_points_fill16<1, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st, (const unsigned short*)nullptr);
+    else hipLaunchKernelGGL((k_points_fill16<3, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st, (const unsigned short*)nullptr);
     PB3D_CHECK_LAUNCH();
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, st.total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));
