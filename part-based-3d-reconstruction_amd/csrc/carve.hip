@@ -582,12 +582,15 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         if (job_skip[j]) continue;
         const u8* ms = d_mask_sub + (i64)j * W * H;
         const u8* mc = d_mask_carve + (i64)j * W * H;
+        PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));          // tables of the job's first rotation, behind the kernels below
         if (wide)
             hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, D / 16);
         else
             hipLaunchKernelGGL(k_part_occ, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D);
         PB3D_CHECK_LAUNCH();
         PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
+        for (int jn = j + 1; jn < njobs; ++jn)                                  // ... and of the next job's, behind this job's last kernels
+            if (!job_skip[jn]) { PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jn])); break; }
         if (wide)
             hipLaunchKernelGGL(k_keep_or16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)carved, ms, (u32x4*)keep, ngroups, D / 16,
                                any ? 0 : 1);

@@ -69,6 +69,17 @@ int pb3d_create(int device, pb3d_ctx** out) {
         pb3d_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         return PB3D_ENODEVICE;
     }
+    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&ctx->rot_cache[k].ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->rot_cache[k].used, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        free(ctx);
+        pb3d_set_error("creating the auxiliary stream failed: %s", hipGetErrorString(e));
+        return PB3D_ENODEVICE;
+    }
     ctx->pinned_bytes = 1 << 16;
     e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -102,10 +113,13 @@ void pb3d_destroy(pb3d_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_stream);
     pb3d_comm_destroy(ctx);
     for (int i = 0; i < PB3D_NSCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(ctx->rot_cache[k].ready); (void)hipEventDestroy(ctx->rot_cache[k].used); }
+    (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -246,6 +260,7 @@ int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
     if (ctx->scratch_bytes[slot] < bytes || !ctx->scratch[slot]) {
         if (ctx->scratch[slot]) {
             PB3D_HIP(hipStreamSynchronize(ctx->stream));
+            PB3D_HIP(hipStreamSynchronize(ctx->aux_stream));
             PB3D_HIP(hipFree(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;
             ctx->scratch_bytes[slot] = 0;

@@ -14,7 +14,7 @@ typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-#define PB3D_NSCRATCH 28
+#define PB3D_NSCRATCH 32
 
 struct pb3d_event {
     hipEvent_t ev;
@@ -51,14 +51,23 @@ struct pb3d_ctx {
         i64 X, Y, Z, n;
         bool valid;
     } deform;
-    // tables of the last generic-angle step (csrc/rotate.hip: launch_table_step) -- reused when the next step has the same key
+    // Tables of generic-angle steps (csrc/rotate.hip: launch_table_step): TWO sets of scratch slots.  A step finds its tables where
+    // an earlier call left them (same key), or where pb3d_prefetch_rotation built them on the auxiliary stream while the previous
+    // step's kernel was running -- the tables depend on (matrix, offset, shape) only, never on data.
     struct RotCache {
         int kind;               // 0: nothing cached
         i64 W, H, D;
         void* cells;
         u64 gen;                // scratch_gen when the tables were built
         double p[8];
-    } rot_cache;
+        u64 stamp;              // last use / build (the older set is rebuilt)
+        bool pending_aux;       // built on aux_stream: the main stream has not waited for `ready` yet
+        hipEvent_t ready;       // recorded on aux_stream after a prefetch
+        hipEvent_t used;        // recorded on the main stream after the last kernel that read this set
+        bool used_valid;
+    } rot_cache[2];
+    u64 rot_stamp;
+    hipStream_t aux_stream;     // table builds that overlap the main stream's kernels
     u64 scratch_gen;            // bumped whenever ANY scratch slot is reallocated (cached tables in other slots may have moved)
     // RCCL (loaded lazily with dlopen; see comm.hip)
     void* rccl_lib;
@@ -125,6 +134,10 @@ __device__ __forceinline__ u32 pb3d_div(u32 n, const pb3d_magic g) {
 }
 
 // ---- kernels' host launchers used across translation units ---------------------------------
+// queue the table build of a LATER generic-angle step on the auxiliary stream (no-op when the step has no tables or they exist)
+int pb3d_prefetch_rotation(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3]);
+// ... of the first rotation of process_voxel_grid(., ., angle_interval)
+int pb3d_prefetch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, int angle_interval);
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
                                const double off[3], const u8* d_mask_wh, u8* d_out, const u8* d_mask_src);
 int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3], const u8* d_mask_wh, const u8* d_rgb_hw3,

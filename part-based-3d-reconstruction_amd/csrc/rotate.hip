@@ -1446,6 +1446,96 @@ bool is_zero(double v) { return v == 0.0; }
 //   fewer planes (or a volume of 4 GiB and more): the 8-plane kernel that evaluates its cells itself.
 static bool table_step_takes_src_mask(i64 W, i64 H, i64 D) { return H >= 32 && W * H * D < (1ll << 32) - 64; }
 
+// ---- the two table sets ------------------------------------------------------------------------------------------------------
+struct TableSet { void *cells, *lutmap, *parts, *tinfo, *runs; };
+static const int kSetSlots[2][5] = {{16, 20, 17, 18, 19}, {26, 27, 28, 29, 30}};
+
+// which tile kernel a table-driven step uses: 1 packed 256-tiles, 2 wide 128-tiles, 3 64-tiles (the parity tests pin each of them on
+// the same grids: ctx->tune_rotate_tile = 64 / 128 / 256)
+static int table_kind(const pb3d_ctx* ctx, i64 W, i64 H, i64 D) {
+    const int pin = ctx->tune_rotate_tile;
+    const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
+    const bool packed_ok = D % 16 == 0 && W * H * D < (1ll << 32) - 64 && H >= 8;
+    // measured (tools/m4bench.py, 45 degrees): 512^3 0.061 ms against 0.113 (64-tiles) / 0.139 (128-tiles); 512 x 278 x 512 0.053 / 0.070 / 0.125
+    if (packed_ok && (pin ? pin == 256 : (W >= 256 && D >= 256 && ptiles * ((H + 7) / 8) >= 64))) return 1;
+    const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
+    if (pin ? pin == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2)) return 2;
+    return 3;
+}
+
+static bool cache_hit(const pb3d_ctx* ctx, const pb3d_ctx::RotCache& rc, int kind, const RotParams& p, i64 W, i64 H, i64 D) {
+    return ctx->tune_misc[4] != 1 && rc.kind == kind && rc.W == W && rc.H == H && rc.D == D && rc.gen == ctx->scratch_gen &&
+           memcmp(rc.p, &p, sizeof(RotParams)) == 0;
+}
+static void cache_set(pb3d_ctx* ctx, pb3d_ctx::RotCache& rc, int kind, const RotParams& p, i64 W, i64 H, i64 D, void* cells) {
+    rc.kind = kind; rc.W = W; rc.H = H; rc.D = D; rc.cells = cells; rc.gen = ctx->scratch_gen; rc.stamp = ++ctx->rot_stamp;
+    static_assert(sizeof(rc.p) == sizeof(RotParams), "RotCache holds one RotParams");
+    memcpy(rc.p, &p, sizeof(RotParams));
+}
+// the main stream is about to read or overwrite set k: a table build that may still run on the auxiliary stream comes first
+static int join_aux(pb3d_ctx* ctx, int k) {
+    pb3d_ctx::RotCache& rc = ctx->rot_cache[k];
+    if (rc.pending_aux) { PB3D_HIP(hipStreamWaitEvent(ctx->stream, rc.ready, 0)); rc.pending_aux = false; }
+    return PB3D_OK;
+}
+static int mark_used(pb3d_ctx* ctx, int k) {
+    PB3D_HIP(hipEventRecord(ctx->rot_cache[k].used, ctx->stream));
+    ctx->rot_cache[k].used_valid = true;
+    return PB3D_OK;
+}
+
+static int packed_alloc(pb3d_ctx* ctx, int k, i64 W, i64 D, TableSet* t) {
+    const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
+    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][0], (size_t)(W * D + XCELLS) * sizeof(CellRec), &t->cells));
+    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][1], 512 * sizeof(u32), &t->lutmap));
+    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][2], (size_t)ptiles * PPARTS * sizeof(PPart), &t->parts));
+    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][3], (size_t)ptiles * sizeof(PTile), &t->tinfo));
+    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][4], (size_t)(W * (D / 16)) * sizeof(RunRec), &t->runs));
+    return PB3D_OK;
+}
+// cells -> tile parts -> tile footprints -> run records of a packed step, queued on `st`
+static int packed_build(pb3d_ctx* ctx, hipStream_t st, const TableSet& t, const RotParams& p, i64 W, i64 H, i64 D) {
+    const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
+    const int ntz = (int)((D + PT - 1) / PT);
+    PB3D_HIP(hipMemsetAsync(t.lutmap, 0, 512 * sizeof(u32), st));
+    hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, st, p, W, D, (CellRec*)t.cells, (u32*)t.lutmap);
+    hipLaunchKernelGGL(k_rot8_parts, dim3((unsigned)(ptiles * PPARTS)), dim3(PTHREADS), 0, st, (const CellRec*)t.cells, W, D, ntz, (PPart*)t.parts);
+    hipLaunchKernelGGL(k_rot8_tiles, dim3((unsigned)ptiles), dim3(PTHREADS), 0, st, (const PPart*)t.parts, (const u32*)t.lutmap, H, D, (PTile*)t.tinfo);
+    hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, st, (const CellRec*)t.cells, (PTile*)t.tinfo, W, D, ntz,
+                       (RunRec*)t.runs);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+static bool generic_step_is_tiled(const double M[9], i64 W, i64 H, i64 D) {
+    const double ext0 = fabs(M[0]) + fabs(M[2]), ext2 = fabs(M[6]) + fabs(M[8]);
+    return ext0 <= 1.45 && ext2 <= 1.45 && W < 65536 && D < 65536 && W * H * D >= (1ll << 21);
+}
+
+// Build the tables of a step that is going to run LATER on the auxiliary stream, while the main stream's kernels run: a chain of
+// steps (process_voxel_grid with a small angle interval, the jobs of part_carve) then never waits for a table (55 us per step, as
+// much as the step itself at 512 x 278 x 512).  Call it right after the current step has been launched: the set the current step
+// reads is the newer one, the other set is rebuilt once the kernels that read IT have finished (event `used`).  No-op when the step
+// is not a packed table step or its tables are already there.
+int pb3d_prefetch_rotation(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3]) {
+    if (ctx->tune_misc[4] != 0 || W * H * D == 0) return PB3D_OK;                              // misc4 = 1: no reuse, 2: no prefetch
+    if (!generic_step_is_tiled(M, W, H, D) || !table_step_takes_src_mask(W, H, D) || table_kind(ctx, W, H, D) != 1) return PB3D_OK;
+    const RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    for (int k = 0; k < 2; ++k)
+        if (cache_hit(ctx, ctx->rot_cache[k], 1, p, W, H, D)) return PB3D_OK;
+    const int k = ctx->rot_cache[0].stamp <= ctx->rot_cache[1].stamp ? 0 : 1;
+    pb3d_ctx::RotCache& rc = ctx->rot_cache[k];
+    rc.kind = 0;
+    TableSet t;
+    PB3D_TRY(packed_alloc(ctx, k, W, D, &t));
+    if (rc.used_valid) PB3D_HIP(hipStreamWaitEvent(ctx->aux_stream, rc.used, 0));             // readers of the old tables first
+    PB3D_TRY(packed_build(ctx, ctx->aux_stream, t, p, W, H, D));
+    PB3D_HIP(hipEventRecord(rc.ready, ctx->aux_stream));
+    rc.pending_aux = true;
+    cache_set(ctx, rc, 1, p, W, H, D, t.cells);
+    return PB3D_OK;
+}
+
 static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const RotParams& p, const u8* d_mask_wh, u8* d_out,
                              int* flag, const u8* d_mask_src) {
     const i64 tiles = ((D + LT - 1) / LT) * ((W + LT - 1) / LT);
@@ -1462,55 +1552,32 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }
-    // ctx->tune_rotate_tile (PB3D_ROTATE_TILE = 64 / 128 / 256, read once in pb3d_create) pins the tile kernel: the parity tests run
-    // all of them on the same grids
-    const int pin = ctx->tune_rotate_tile;
     const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
-    const bool packed_ok = D % 16 == 0 && W * H * D < (1ll << 32) - 64 && H >= 8;
-    // measured (tools/m4bench.py, 45 degrees): 512^3 0.061 ms against 0.113 (64-tiles) / 0.139 (128-tiles); 512 x 278 x 512 0.053 / 0.070 / 0.125
-    const bool packed = packed_ok && (pin ? pin == 256 : (W >= 256 && D >= 256 && ptiles * ((H + 7) / 8) >= 64));
     const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
-    const bool wide = !packed && (pin ? pin == 128 : (W >= 256 && D >= 256 && xtiles * ((H + 63) / 64) >= (i64)ctx->cus * 2));
     // The step tables (cells, tile footprints, run records) depend on (matrix, offset, W, H, D) only.  A caller that repeats a step --
-    // part_carve jobs with one angle, the same process_voxel_grid on grid after grid -- finds them where the last call left them:
-    // the scratch slots are private to this path and the stream is in order.  tune misc4 = 1 switches the reuse off.
-    const int kind = packed ? 1 : (wide ? 2 : 3);
-    void *cells, *lutmap = nullptr;
-    PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
-    if (packed) PB3D_TRY(pb3d_scratch(ctx, 20, 512 * sizeof(u32), &lutmap));
-    pb3d_ctx::RotCache& rc = ctx->rot_cache;
-    const bool cached = ctx->tune_misc[4] != 1 && rc.kind == kind && rc.W == W && rc.H == H && rc.D == D && rc.cells == cells &&
-                        memcmp(rc.p, &p, sizeof(RotParams)) == 0 && rc.gen == ctx->scratch_gen;
-    rc.kind = 0;                                        // invalid until this call has queued everything
-    if (!cached) {
-        if (packed) PB3D_HIP(hipMemsetAsync(lutmap, 0, 512 * sizeof(u32), ctx->stream));
-        hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)lutmap);
-        PB3D_CHECK_LAUNCH();
-    }
-    auto remember = [&]() {
-        rc.kind = kind; rc.W = W; rc.H = H; rc.D = D; rc.cells = cells; rc.gen = ctx->scratch_gen;
-        static_assert(sizeof(rc.p) == sizeof(RotParams), "RotCache holds one RotParams");
-        memcpy(rc.p, &p, sizeof(RotParams));
-    };
+    // part_carve jobs with one angle, the same process_voxel_grid on grid after grid -- finds them where an earlier call left them
+    // (two sets of private scratch slots; the stream is in order); a chain of different steps finds them where
+    // pb3d_prefetch_rotation built them meanwhile.  tune misc4 = 1 switches the reuse off, 2 the prefetch.
+    const int kind = table_kind(ctx, W, H, D);
+    const bool packed = kind == 1, wide = kind == 2;
     if (packed) {
         if (!ctx->packed_lds_set) {
             PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
             PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
             ctx->packed_lds_set = true;
         }
+        int k = -1;
+        for (int q = 0; q < 2; ++q)
+            if (cache_hit(ctx, ctx->rot_cache[q], 1, p, W, H, D)) k = q;
+        const bool cached = k >= 0;
+        if (!cached) k = ctx->rot_cache[0].stamp <= ctx->rot_cache[1].stamp ? 0 : 1;
+        pb3d_ctx::RotCache& rc = ctx->rot_cache[k];
+        PB3D_TRY(join_aux(ctx, k));
+        TableSet t;
+        if (!cached) rc.kind = 0;                           // invalid until this call has queued everything
+        PB3D_TRY(packed_alloc(ctx, k, W, D, &t));
+        if (!cached) PB3D_TRY(packed_build(ctx, ctx->stream, t, p, W, H, D));
         const int ntz = (int)((D + PT - 1) / PT);
-        void *parts, *tinfo, *runs;
-        PB3D_TRY(pb3d_scratch(ctx, 17, (size_t)ptiles * PPARTS * sizeof(PPart), &parts));
-        PB3D_TRY(pb3d_scratch(ctx, 18, (size_t)ptiles * sizeof(PTile), &tinfo));
-        PB3D_TRY(pb3d_scratch(ctx, 19, (size_t)(W * (D / 16)) * sizeof(RunRec), &runs));
-        if (!cached) {
-            hipLaunchKernelGGL(k_rot8_parts, dim3((unsigned)(ptiles * PPARTS)), dim3(PTHREADS), 0, ctx->stream, (const CellRec*)cells, W, D, ntz, (PPart*)parts);
-            hipLaunchKernelGGL(k_rot8_tiles, dim3((unsigned)ptiles), dim3(PTHREADS), 0, ctx->stream, (const PPart*)parts, (const u32*)lutmap, H, D,
-                               (PTile*)tinfo);
-            hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, ctx->stream, (const CellRec*)cells, (PTile*)tinfo, W, D,
-                               ntz, (RunRec*)runs);
-            PB3D_CHECK_LAUNCH();
-        }
         // planes per workgroup: 8 = one pass (measured at 1024^3, 45 degrees, warm tables: 8 planes 0.46 ms, 16 / 32 planes 0.50 --
         // the more workgroups, the better their stage and evaluate phases interleave across the chip)
         int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : 8;
@@ -1518,12 +1585,25 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         const i64 nblk = 8 * ptiles * ((nchunks + 7) / 8);
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
         auto kern = d_mask_src ? k_rotate_bits8p<true> : k_rotate_bits8p<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)runs,
-                           (const PTile*)tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0]);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)t.runs,
+                           (const PTile*)t.tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0]);
         PB3D_CHECK_LAUNCH();
-        remember();
+        cache_set(ctx, rc, 1, p, W, H, D, t.cells);
+        PB3D_TRY(mark_used(ctx, k));
         return PB3D_OK;
     }
+    // the other two tile kernels keep their cells (and tile rows) in the slots of set 0
+    pb3d_ctx::RotCache& rc = ctx->rot_cache[0];
+    PB3D_TRY(join_aux(ctx, 0));
+    void* cells;
+    PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
+    const bool cached = cache_hit(ctx, rc, kind, p, W, H, D) && rc.cells == cells;
+    rc.kind = 0;                                            // invalid until this call has queued everything
+    if (!cached) {
+        hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)nullptr);
+        PB3D_CHECK_LAUNCH();
+    }
+    auto remember = [&]() { cache_set(ctx, rc, kind, p, W, H, D, cells); return mark_used(ctx, 0); };
     if (wide) {
         if (!ctx->wide_lds_set) {       // > 64 KiB of LDS per workgroup has to be allowed once per device
             PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits16w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLds));
@@ -1553,7 +1633,7 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
                            TYW, (int)((D + LT - 1) / LT), (int)tiles, flag, d_mask_src);
     }
     PB3D_CHECK_LAUNCH();
-    remember();
+    PB3D_TRY(remember());
     return PB3D_OK;
 }
 
@@ -1566,7 +1646,8 @@ int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9]
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     void* cells;
     PB3D_TRY(pb3d_scratch(ctx, 16, (size_t)(W * D + XCELLS) * sizeof(CellRec), &cells));
-    ctx->rot_cache.kind = 0;                            // slot 16 is about to hold another step's cells
+    PB3D_TRY(join_aux(ctx, 0));
+    ctx->rot_cache[0].kind = 0;                         // slots 16 / 17 are about to hold another step's cells
     hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, ctx->stream, p, W, D, (CellRec*)cells, (u32*)nullptr);
     PB3D_CHECK_LAUNCH();
     dim3 grid((unsigned)((W * (D / 16) + 255) / 256), (unsigned)((H + 31) / 32));
@@ -1582,9 +1663,17 @@ int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9]
 }
 
 bool pb3d_generic_step_takes_src_mask(const double M[9], i64 W, i64 H, i64 D) {
-    const double ext0 = fabs(M[0]) + fabs(M[2]), ext2 = fabs(M[6]) + fabs(M[8]);
-    const bool tiled = ext0 <= 1.45 && ext2 <= 1.45 && W < 65536 && D < 65536 && W * H * D >= (1ll << 21);
-    return tiled && table_step_takes_src_mask(W, H, D);
+    return generic_step_is_tiled(M, W, H, D) && table_step_takes_src_mask(W, H, D);
+}
+
+int pb3d_prefetch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, int angle_interval) {
+    if (angle_interval <= 0 || angle_interval > 90 || W * H * D == 0) return PB3D_OK;
+    const i64 shape[3] = {W, H, D};
+    double M[9], off[3];
+    PB3D_TRY(pb3d_rotinv(angle_interval, M));
+    PB3D_TRY(pb3d_offset(M, shape, off));
+    if (pb3d_is_perm_step(M, off, W, D)) return PB3D_OK;
+    return pb3d_prefetch_rotation(ctx, W, H, D, M, off);
 }
 
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
@@ -1598,8 +1687,7 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     // first one met a value > 1 (device-side flag, no host round trip).  Small grids (launch-bound):
     // the arithmetic kernel alone.  The footprint of a 64 x 64 tile must fit the LDS box: true for
     // rotations (row sums of |M| <= sqrt 2).
-    const double ext0 = fabs(M[0]) + fabs(M[2]), ext2 = fabs(M[6]) + fabs(M[8]);
-    const bool tiled = ext0 <= 1.45 && ext2 <= 1.45 && W < 65536 && D < 65536 && W * H * D >= (1ll << 21);
+    const bool tiled = generic_step_is_tiled(M, W, H, D);
     int* flag = nullptr;
     if (tiled) {
         void* f;
@@ -1682,6 +1770,12 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
                 PB3D_TRY(pb3d_launch_rotate_perm(ctx, src, W, H, D, M, off, (fuse_first && s == 1) ? d_mask_wh : nullptr, d_mask_wh, dst));
             else
                 PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, d_mask_wh, dst, (fuse_first && s == 1) ? d_mask_wh : nullptr));
+        }
+        if (s + 1 < nsteps) {                               // the next step's tables are built while this step's kernel runs
+            double Mn[9], offn[3];
+            PB3D_TRY(pb3d_rotinv((s + 1) * angle_interval, Mn));
+            PB3D_TRY(pb3d_offset(Mn, shape, offn));
+            if (!pb3d_is_perm_step(Mn, offn, W, D)) PB3D_TRY(pb3d_prefetch_rotation(ctx, W, H, D, Mn, offn));
         }
         src = dst;
     }

@@ -33,6 +33,8 @@ def main():
         if r == 0: D = W
         if r == 1: W = D = int(rng.choice([16, 32, 48, 64, 96, 128, 160, 256]))
         if r == 2: D = W + 2 * int(rng.integers(-10, 10)); D = max(1, D)
+        if n % 11 == 3:      # rows that are not whole lines on H * D % 128 == 0 grids: the flat 90-degree kernels (k_rot90_flat, k_global_carve90f)
+            H = int(rng.choice([16, 32, 64, 128])); W = D = int(rng.integers(129, 300)); D += 2 * int(rng.integers(0, 3))
         ai = int(rng.choice([90, 90, 60, 45, 30, 20, 10, 120, 7]))
         dens = rng.uniform(0.05, 0.95)
         g = (rng.random((W, H, D)) < dens).astype(np.uint8) if n % 6 else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
