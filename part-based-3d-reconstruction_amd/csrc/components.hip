@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_extrude_z(const u8* __restrict__ src, u
     const int lane = threadIdx.x & 63;
     const i64 col = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= W * H) return;
+    if (!valid_wh[col]) return;     // wave-uniform: nothing is painted in this column, so its surface is not looked for either
     const u8* s = src + col * D * 3;
     i64 start = plus ? 0 : D - 1;   // argmax of an all-zero column is index 0 (of the possibly reversed view)
     for (i64 base = 0; base < D; base += 64) {
@@ -145,7 +146,6 @@ __global__ __launch_bounds__(256) void k_extrude_z(const u8* __restrict__ src, u
             break;
         }
     }
-    if (!valid_wh[col]) return;
     for (int d = lane; d < depth; d += 64) {
         const i64 z = plus ? start + d : start - d;
         if (z < 0 || z >= D) continue;
@@ -162,13 +162,13 @@ __global__ __launch_bounds__(256) void k_extrude_x(const u8* __restrict__ src, u
     const i64 n = H * D;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         const i64 y = i / D, z = i - y * D;
+        if (!valid_hw[y * Wmask + z]) continue;          // only the columns under the mask are scanned (a door, a few windows)
         i64 start = plus ? 0 : W - 1;
         for (i64 j = 0; j < W; ++j) {
             const i64 x = plus ? j : W - 1 - j;
             const u8* p = src + ((x * H + y) * D + z) * 3;
             if (p[0] | p[1] | p[2]) { start = x; break; }
         }
-        if (!valid_hw[y * Wmask + z]) continue;
         for (int d = 0; d < depth; ++d) {
             const i64 x = plus ? start + d : start - d;
             if (x < 0 || x >= W) continue;

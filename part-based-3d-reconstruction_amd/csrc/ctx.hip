@@ -4,6 +4,8 @@
 
 #include "pb3d_internal.h"
 
+static int pool_flush(pb3d_ctx* ctx);
+
 static thread_local char g_err[512] = "";
 
 void pb3d_set_error(const char* fmt, ...) {
@@ -80,6 +82,10 @@ int pb3d_create(int device, pb3d_ctx** out) {
         pb3d_set_error("creating the auxiliary stream failed: %s", hipGetErrorString(e));
         return PB3D_ENODEVICE;
     }
+    {
+        const char* v = getenv("PB3D_DEVICE_POOL_MB");
+        ctx->pool_cap = v ? (size_t)(atoll(v) < 0 ? 0 : atoll(v)) << 20 : (size_t)prop.totalGlobalMem / 4;
+    }
     ctx->pinned_bytes = 1 << 16;
     e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -115,6 +121,7 @@ void pb3d_destroy(pb3d_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->aux_stream);
     pb3d_comm_destroy(ctx);
+    (void)pool_flush(ctx);
     for (int i = 0; i < PB3D_NSCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -142,19 +149,76 @@ int pb3d_sync(pb3d_ctx* ctx) {
     return PB3D_OK;
 }
 
+// give every cached device block back to the driver (when a hipMalloc fails, and at destroy)
+static int pool_flush(pb3d_ctx* ctx) {
+    if (ctx->pool_nfree == 0) return PB3D_OK;
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->pool_nfree; ++i) (void)hipFree(ctx->pool_free[i].p);
+    ctx->pool_nfree = 0;
+    ctx->pool_cached = 0;
+    return PB3D_OK;
+}
+
+// hipMalloc that empties the pool and tries once more before giving up
+static hipError_t pool_malloc(pb3d_ctx* ctx, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && ctx->pool_nfree > 0) {
+        (void)hipGetLastError();
+        if (pool_flush(ctx) == PB3D_OK) e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
 int pb3d_dev_alloc(pb3d_ctx* ctx, size_t bytes, void** dptr) {
     PB3D_REQUIRE(ctx != nullptr && dptr != nullptr, "pb3d_dev_alloc: null argument");
     *dptr = nullptr;
     PB3D_HIP(hipSetDevice(ctx->device));
     // round up so that 16-byte vector tails never leave the allocation
     size_t padded = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
-    PB3D_HIP(hipMalloc(dptr, padded));
+    // best fit among the cached blocks: at least the request, at most an eighth (+ 1 MiB) more
+    int best = -1;
+    for (int i = 0; i < ctx->pool_nfree; ++i) {
+        const size_t b = ctx->pool_free[i].bytes;
+        if (b >= padded && b <= padded + padded / 8 + (1u << 20) && (best < 0 || b < ctx->pool_free[best].bytes)) best = i;
+    }
+    void* p = nullptr;
+    size_t got = padded;
+    if (best >= 0) {
+        p = ctx->pool_free[best].p; got = ctx->pool_free[best].bytes;
+        ctx->pool_cached -= got;
+        ctx->pool_free[best] = ctx->pool_free[--ctx->pool_nfree];
+    } else {
+        PB3D_HIP(pool_malloc(ctx, &p, padded));
+    }
+    if (ctx->pool_cap > 0) {
+        if (ctx->pool_nlive < PB3D_POOL_LIVE) ctx->pool_live[ctx->pool_nlive++] = {p, got, 0};
+        // (a full table only means this block will be released with hipFree instead of being kept)
+    }
+    *dptr = p;
     return PB3D_OK;
 }
 
 int pb3d_dev_free(pb3d_ctx* ctx, void* dptr) {
     PB3D_REQUIRE(ctx != nullptr, "pb3d_dev_free: null context");
     if (!dptr) return PB3D_OK;
+    size_t bytes = 0;
+    for (int i = ctx->pool_nlive - 1; i >= 0; --i)             // the most recent allocations are freed first
+        if (ctx->pool_live[i].p == dptr) { bytes = ctx->pool_live[i].bytes; ctx->pool_live[i] = ctx->pool_live[--ctx->pool_nlive]; break; }
+    if (bytes > 0 && bytes <= ctx->pool_cap) {
+        // make room: the oldest cached blocks go back to the driver (that needs the stream idle: their last users are on it)
+        while (ctx->pool_nfree > 0 && (ctx->pool_cached + bytes > ctx->pool_cap || ctx->pool_nfree == PB3D_POOL_SLOTS)) {
+            int old = 0;
+            for (int i = 1; i < ctx->pool_nfree; ++i)
+                if (ctx->pool_free[i].stamp < ctx->pool_free[old].stamp) old = i;
+            PB3D_HIP(hipStreamSynchronize(ctx->stream));
+            PB3D_HIP(hipFree(ctx->pool_free[old].p));
+            ctx->pool_cached -= ctx->pool_free[old].bytes;
+            ctx->pool_free[old] = ctx->pool_free[--ctx->pool_nfree];
+        }
+        ctx->pool_free[ctx->pool_nfree++] = {dptr, bytes, ++ctx->pool_stamp};
+        ctx->pool_cached += bytes;
+        return PB3D_OK;
+    }
     PB3D_HIP(hipStreamSynchronize(ctx->stream));
     PB3D_HIP(hipFree(dptr));
     return PB3D_OK;
@@ -266,7 +330,7 @@ int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
             ctx->scratch_bytes[slot] = 0;
         }
         size_t padded = ((bytes ? bytes : 1) + 4095) & ~(size_t)4095;
-        PB3D_HIP(hipMalloc(&ctx->scratch[slot], padded));
+        PB3D_HIP(pool_malloc(ctx, &ctx->scratch[slot], padded));
         ctx->scratch_bytes[slot] = padded;
         ++ctx->scratch_gen;
     }

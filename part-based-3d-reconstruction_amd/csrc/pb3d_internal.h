@@ -15,6 +15,8 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 
 #define PB3D_NSCRATCH 32
+#define PB3D_POOL_SLOTS 64
+#define PB3D_POOL_LIVE 4096
 
 struct pb3d_event {
     hipEvent_t ev;
@@ -68,6 +70,17 @@ struct pb3d_ctx {
     } rot_cache[2];
     u64 rot_stamp;
     hipStream_t aux_stream;     // table builds that overlap the main stream's kernels
+    // Device block pool behind pb3d_dev_alloc / pb3d_dev_free: a freed block is kept (no hipFree, no stream synchronisation) and handed
+    // to the next request of about its size.  Everything that touches such a block runs on ctx->stream, in order, so a re-used block
+    // is never written before its previous reader has finished.  The NumPy-signature API allocates and frees a volume-sized buffer
+    // or two per call: with hipMalloc / hipFree (which waits for the device) that was most of a notebook-1 run's wall time.
+    struct PoolBlock { void* p; size_t bytes; u64 stamp; };
+    PoolBlock pool_free[PB3D_POOL_SLOTS];
+    int pool_nfree;
+    PoolBlock pool_live[PB3D_POOL_LIVE];
+    int pool_nlive;
+    size_t pool_cached, pool_cap;       // bytes held in pool_free; its limit (PB3D_DEVICE_POOL_MB, default a quarter of the HBM, 0 = off)
+    u64 pool_stamp;
     u64 scratch_gen;            // bumped whenever ANY scratch slot is reallocated (cached tables in other slots may have moved)
     // RCCL (loaded lazily with dlopen; see comm.hip)
     void* rccl_lib;
