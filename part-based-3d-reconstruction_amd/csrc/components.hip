@@ -198,6 +198,35 @@ __global__ __launch_bounds__(256) void k_orient(const u8* __restrict__ grid, u8*
     }
 }
 
+// the same permutation with dword accesses on both sides (W % 4 == 0 and D % 4 == 0, 4-byte aligned buffers): a 32 x 32 tile's
+// source and destination rows are 96 bytes = 24 aligned dwords; a destination dword gathers its four bytes from LDS.  The byte
+// version spends 12 byte loads and 12 byte stores per thread and tile (0.39 ms at 512 x 278 x 512).
+__global__ __launch_bounds__(256) void k_orient4(const u8* __restrict__ grid, u8* __restrict__ out, i64 W, i64 H, i64 D) {
+    __shared__ __attribute__((aligned(4))) u8 t[32][32 * 3 + 4];
+    const i64 x0 = (i64)blockIdx.x * 32, z0 = (i64)blockIdx.y * 32, y = blockIdx.z;
+    for (int i = threadIdx.x; i < 32 * 24; i += 256) {          // source rows: fixed x, 32 z * 3 bytes = 24 dwords
+        const int xl = i / 24, k = i - xl * 24;
+        const i64 x = x0 + xl, zb = z0 * 3 + 4 * k;
+        u32 v = 0;
+        if (x < W && zb < D * 3) v = *(const u32*)(grid + ((x * H + y) * D) * 3 + zb);       // D % 4 == 0: a dword is inside the row or past it
+        *(u32*)&t[xl][4 * k] = v;
+    }
+    __syncthreads();
+    const i64 yb = H - 1 - y;
+    for (int i = threadIdx.x; i < 32 * 24; i += 256) {          // destination rows: fixed z, 32 x * 3 bytes = 24 dwords
+        const int zl = i / 24, k = i - zl * 24;
+        const i64 z = z0 + zl, xb = x0 * 3 + 4 * k;
+        if (z >= D || xb >= W * 3) continue;
+        u32 v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = 4 * k + q, xl = b / 3, c = b - 3 * xl;
+            v |= (u32)t[xl][zl * 3 + c] << (8 * q);
+        }
+        *(u32*)(out + ((z * H + yb) * W) * 3 + xb) = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -290,7 +319,10 @@ int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t
     PB3D_REQUIRE(d_grid_rgb && d_out && d_grid_rgb != d_out, "pb3d_orient: null or aliased buffer");
     PB3D_REQUIRE(H <= 65535 && (D + 31) / 32 <= 65535, "pb3d_orient: grid too large");
     dim3 grid((unsigned)((W + 31) / 32), (unsigned)((D + 31) / 32), (unsigned)H);
-    hipLaunchKernelGGL(k_orient, grid, dim3(256), 0, ctx->stream, d_grid_rgb, d_out, W, H, D);
+    if (W % 4 == 0 && D % 4 == 0 && ((((uintptr_t)d_grid_rgb) | ((uintptr_t)d_out)) & 3u) == 0)
+        hipLaunchKernelGGL(k_orient4, grid, dim3(256), 0, ctx->stream, d_grid_rgb, d_out, W, H, D);
+    else
+        hipLaunchKernelGGL(k_orient, grid, dim3(256), 0, ctx->stream, d_grid_rgb, d_out, W, H, D);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }

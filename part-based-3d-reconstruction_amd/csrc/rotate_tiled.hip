@@ -874,6 +874,159 @@ __global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, 
     }
 }
 
+// K5 for rows that are not whole lines, FLAT form (H * D % 128 == 0; see k_rot90_flat): a tile is 128 x-rows x one SEGMENT of 128
+// voxels of the rows' (y, z) stream, f = y * D + z = 128 s + j.  Source row of byte j: n0 = c0 - z_j of plane y_j; both the colour
+// rows the keep bits are cut from and the rows they are written to are then whole aligned lines (384 bytes per row and segment), so
+// phase B has neither ragged pieces nor partial stores.  A 16-voxel run that straddles a row end takes its destination job bits
+// from two planes.
+__global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colored, const u32* __restrict__ A, const u32* __restrict__ vbits, int nw,
+                                                     int c0, int c2, i64 W, i64 H, i64 D, int TS, u8* __restrict__ out, TileMap tm, pb3d_magic mD,
+                                                     i64 nseg) {
+    __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
+    __shared__ u32 asrc[128];
+    __shared__ __attribute__((aligned(8))) unsigned short keepb[128 * 8 + 4];
+    const int tid = threadIdx.x;
+    i64 zt, xt, sc;
+    if (!tile_of_block(tm, &zt, &xt, &sc)) return;                          // whole workgroup, before any barrier
+    const i64 x0 = xt * 128;
+    const i64 s_beg = sc * TS;
+    const i64 s_end = s_beg + TS < nseg ? s_beg + TS : nseg;
+    const i64 HD = H * D;
+    const int cb = tid & 7;
+    const i64 scol = x0 + c2 + 16 * cb;
+    const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
+    const i64 nvox_all = W * HD;
+    const int zg = tid & 7, xg = tid >> 3;
+    const int g = 7 - zg;
+    const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
+    auto vwin = [&](i64 x, i64 zlo) -> u32 {
+        if (zlo <= -16 || zlo >= D) return 0u;
+        const i64 zs = zlo < 0 ? 0 : zlo;
+        const u32* vr = vbits + x * nw + (zs >> 5);
+        u32 v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zs & 31)) & 0xffffu;
+        if (zlo < 0) v = (v << (int)(-zlo)) & 0xffffu;
+        return v;
+    };
+    u32x4 stg[12];
+    u32 stg_a = 0;
+    u32 stg_va[4], stg_da[4], stg_db[4];       // per output row: validity bits of the run, destination job bits of its two planes
+    int stg_nA = 16;
+    auto load_seg = [&](i64 s) {
+        const bool live = s < s_end;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 3) + 32 * j;
+            const u32 f = (u32)(128 * s) + (u32)(127 - lr);
+            const u32 y = pb3d_div(f, mD), z = f - y * mD.d;
+            const i64 n0 = (i64)c0 - (i64)z;
+            const bool ok = live && cmode && n0 >= 0 && n0 < W;
+            const i64 v0s = (n0 * H + (i64)y) * D + scol;                  // first source voxel of the piece
+            const bool whole = cmode == 2 || (v0s >= 0 && v0s + 16 <= nvox_all);
+            const u8* sp8 = colored + v0s * 3;
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) stg[3 * j + k] = ok ? ((const u32x4_u*)sp8)[k] : (u32x4)(0u);
+            } else {
+                u32 t12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok)
+                    for (int b = 0; b < 48; ++b)
+                        if (scol + b / 3 >= 0 && scol + b / 3 < D) t12[b >> 2] |= (u32)sp8[b] << (8 * (b & 3));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { stg[3 * j + k].x = t12[4 * k]; stg[3 * j + k].y = t12[4 * k + 1]; stg[3 * j + k].z = t12[4 * k + 2]; stg[3 * j + k].w = t12[4 * k + 3]; }
+            }
+        }
+        if (tid < 128) {                                                   // job bits of the source pixel of local row tid
+            const u32 f = (u32)(128 * s) + (u32)(127 - tid);
+            const u32 y = live ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+            const i64 n0 = (i64)c0 - (i64)z;
+            stg_a = (live && n0 >= 0 && n0 < W) ? A[n0 * H + (i64)y] : 0u;
+        }
+        const u32 f = (u32)(128 * s) + (u32)(16 * zg);
+        const u32 y = live ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+        stg_nA = (i64)z + 16 <= D ? 16 : (int)(D - (i64)z);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            u32 bits = 0, da = 0, db = 0;
+            if (live && x < W) {
+                bits = vwin(x, (i64)z);
+                if (stg_nA < 16) bits |= vwin(x, (i64)z - D);
+                if (bits) { da = A[x * H + (i64)y]; if (stg_nA < 16) db = A[x * H + (i64)y + 1]; }
+            }
+            stg_va[i] = bits; stg_da[i] = da; stg_db[i] = db;
+        }
+    };
+    load_seg(s_beg);
+    for (i64 s = s_beg; s < s_end; ++s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 3) + 32 * j;
+            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = occ16_of(stg[3 * j], stg[3 * j + 1], stg[3 * j + 2]);
+        }
+        if (tid < 128) asrc[tid] = stg_a;
+        u32 va[4], da[4], db[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { va[i] = stg_va[i]; da[i] = stg_da[i]; db[i] = stg_db[i]; }
+        const int nA = stg_nA;
+        __syncthreads();
+        load_seg(s + 1);
+        // ---- phase A: keep bits of this thread's 4 rows x 16 voxels of the segment
+        u32 d[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32 k16 = 0;
+            if (va[i] && (da[i] | db[i])) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const u32 ob = (d[15 - q] >> (8 * i)) & 0xffu;               // occ[c0 - z, y, x + c2]
+                    const u32 as = asrc[16 * g + 15 - q];
+                    if (ob && (as & (q < nA ? da[i] : db[i]))) k16 |= 1u << q;
+                }
+                k16 &= va[i];
+            }
+            keepb[(4 * xg + i) * 8 + zg] = (unsigned short)k16;
+        }
+        __syncthreads();
+        // ---- phase B: row r = (tid >> 3) + 32 j, pieces pl, pl + 8, pl + 16 of its 384 bytes: whole aligned lines on both sides
+        const int pl = tid & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (tid >> 3) + 32 * j;
+            const i64 x = x0 + r;
+            if (x >= W) continue;
+            const i64 rowoff = (x * HD + 128 * s) * 3;
+            const unsigned short* kb = keepb + r * 8;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int pc = pl + 8 * kk;
+                const int v0 = (16 * pc) / 3;
+                const u32 ph = (u32)(pc % 3);
+                const int wi = v0 >> 4;
+                const u32 win = (u32)kb[wi] | ((wi < 7 ? (u32)kb[wi + 1] : 0u) << 16);
+                const u32 kb6 = (win >> (v0 & 15)) & 0x3fu;
+                u32x4 val = (u32x4)(0u);
+                if (kb6) {
+                    const u32x4 src = *(const u32x4*)(colored + rowoff + 16 * pc);
+                    u32 m[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
+                    const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
+                              w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
+                              w4 = m[5] & 0x0000ffffu;
+                    val.x = src.x & __builtin_amdgcn_alignbyte(w1, w0, ph);
+                    val.y = src.y & __builtin_amdgcn_alignbyte(w2, w1, ph);
+                    val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
+                    val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
+                }
+                __builtin_nontemporal_store(val, (u32x4*)(out + rowoff + 16 * pc));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_sub, const u8* __restrict__ mask_carve,
                                                     const int* __restrict__ job_on, int nj, i64 npix, u32* __restrict__ A) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (i64)gridDim.x * blockDim.x) {
@@ -1058,6 +1211,16 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
                        (const int*)jon, njobs, W * H, (u32*)A);
     PB3D_CHECK_LAUNCH();
     if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
+    if (rgbsrc && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && H * D < (1ll << 31) && ctx->tune_misc[2] != 2 &&
+        ((((uintptr_t)d_colored) | ((uintptr_t)d_out)) & 15u) == 0) {            // rows that are not whole lines: the (y, z) stream of every x-row in whole lines
+        const i64 nseg = H * D / 128, nxt = (W + 127) / 128;
+        const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
+        const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
+        hipLaunchKernelGGL(k_part90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_colored, (const u32*)A, (const u32*)bits, nw, pm.c0, pm.c2, W,
+                           H, D, TS, d_out, fm, pb3d_make_magic((u32)D), nseg);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
     const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
     const int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_misc[1]);
     const TileMap tm = {(int)((D + 127) / 128), (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2]};

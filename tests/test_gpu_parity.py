@@ -696,14 +696,23 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
     PC = oracle.PART_COLORS
     names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
     pal = np.array([PC[n] for n in names] + [(0, 0, 0), (9, 9, 9)], np.uint8)
-    for (W, H, D) in [(37, 9, 51), (51, 5, 37), (130, 6, 62), (355, 4, 355), (129, 3, 131), (16, 7, 48), (200, 3, 72)]:
+    for (W, H, D) in [(37, 9, 51), (51, 5, 37), (130, 6, 62), (355, 4, 355), (129, 3, 131), (16, 7, 48), (200, 3, 72),
+                      # H * D % 128 == 0 with rows that are not whole lines: the flat form (k_part90_flat: segments of each x-row's (y, z)
+                      # stream, runs that straddle two planes); tune misc2 = 2 keeps the plane-wise kernel
+                      (355, 128, 355), (131, 256, 131), (136, 128, 200), (200, 128, 136), (141, 384, 141), (300, 32, 172)]:
         sem = pal[rng.integers(0, 7, (H, W))]                              # (H,W,3) semantic mask: part colours + black
         colored = pal[rng.integers(0, len(pal), (W, H, D))]                # (W,H,D,3): part colours, black, a foreign colour
         colored[rng.random((W, H, D)) < 0.3] = 0
+        lines = D % 128 != 0 and (H * D) % 128 == 0 and D >= 128
         for jobs in (JOBS_NB1, JOBS_MIXED):
-            got = pb3d_gpu.part_carve(colored, sem, jobs)
             want = oracle.part_carve(colored, sem, jobs)
-            assert np.array_equal(got, want), (W, H, D, len(jobs), int((got != want).sum()))
+            for misc2 in ((0, 2) if lines else (0,)):
+                pb3d_gpu._lib.set_tuning("misc2", misc2)
+                try:
+                    got = pb3d_gpu.part_carve(colored, sem, jobs)
+                finally:
+                    pb3d_gpu._lib.set_tuning("misc2", 0)
+                assert np.array_equal(got, want), (W, H, D, len(jobs), misc2, int((got != want).sum()))
 
 
 @pytest.mark.gpu
