@@ -1377,9 +1377,16 @@ __global__ __launch_bounds__(256) void k_first_step(const CellRec* __restrict__ 
     const int np = (int)(H - y0 < 32 ? H - y0 : 32);
     for (i64 x = threadIdx.x; x < W; x += 256) mb[x] = planebits[(i64)blockIdx.y * W + x];
     __syncthreads();
+    // RGBOUT: a lane's 48 colour bytes go through a wave-private LDS window so that every store instruction writes the wave's
+    // 16-byte chunks in address order (1 KiB contiguous per instruction where the lanes' runs follow each other; three stores of
+    // 16 bytes every 48 touched each line three times)
+    __shared__ u32x4 xch[RGBOUT ? 4 * 192 : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const i64 nzr = D / 16;
-    const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (g >= W * nzr) return;
+    const i64 g0 = (i64)blockIdx.x * 256 + threadIdx.x;
+    const bool live = g0 < W * nzr;
+    if (!RGBOUT && !live) return;
+    const i64 g = live ? g0 : W * nzr - 1;               // a lane past the grid works on a copy of the last run and stores nothing
     const i64 x = g / nzr, z0 = 16 * (g - x * nzr);
     const u32 dst = mb[x];
     u32 bits[16];
@@ -1429,9 +1436,16 @@ __global__ __launch_bounds__(256) void k_first_step(const CellRec* __restrict__ 
                 u32 w[12];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rgb_of_occ4(oc[i], C0, C1, C2, w + 3 * i);
-                u32x4* op = (u32x4*)(out + 3 * (y * D + (i64)ooff));
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { u32x4 r; r.x = w[4 * k]; r.y = w[4 * k + 1]; r.z = w[4 * k + 2]; r.w = w[4 * k + 3]; op[k] = r; }
+                for (int k = 0; k < 3; ++k) { u32x4 r; r.x = w[4 * k]; r.y = w[4 * k + 1]; r.z = w[4 * k + 2]; r.w = w[4 * k + 3]; xch[wv * 192 + 3 * lane + k] = r; }
+                const u32 myoff = live ? ooff : 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int c = 64 * k + lane, L = c / 3, part = c - 3 * L;           // chunk c of the wave's 3 KiB belongs to lane L
+                    const u32x4 v = xch[wv * 192 + c];
+                    const u32 lo = (u32)__shfl((int)myoff, L);
+                    if (lo != 0xffffffffu) *(u32x4*)(out + 3 * (y * D + (i64)lo) + 16 * part) = v;
+                }
             }
         }
     }

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
                                                i64 W, i64 H, i64 D, int TY, TileMap tm, const u8* __restrict__ rgb_hw3 = nullptr) {
     __shared__ __attribute__((aligned(16))) u8 tiles[2][128 * 128];
+    __shared__ u32x4 xch[RGBOUT ? 4 * 192 : 1];        // RGBOUT: wave-private exchange window of the colour stores (see below)
     const int tid = threadIdx.x;
     i64 zt, xt, yc;
     if (!tile_of_block(tm, &zt, &xt, &yc)) return;                          // whole workgroup, before any barrier
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const i64 x = x0 + 4 * xg + i;
-                if (x >= W || zlo >= D || (ALIGNZ && zlo <= -16)) continue;
+                const bool act = !(x >= W || zlo >= D || (ALIGNZ && zlo <= -16));
+                if (!RGBOUT && !act) continue;          // (RGBOUT: every lane takes part in the exchange below)
                 const u32 vbi = vcur[i];
                 u32x4 r = (u32x4)(0u);
                 if ((mkc >> (4 + i)) & 1u) {
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                     }
                 }
                 if (RGBOUT) {
-                    const u8* px = rgb_hw3 + (y * W + x) * 3;
+                    const u8* px = rgb_hw3 + (y * W + (act ? x : 0)) * 3;
                     const u32 R = px[0], G = px[1], B = px[2];
                     const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
                     const u32 oc[4] = {r.x, r.y, r.z, r.w};
@@ -507,9 +509,20 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                         e = (e >> 7) * 0xffu;
                         w[3 * q] = perm(e, e, 0x01000000u) & C0; w[3 * q + 1] = perm(e, e, 0x02020101u) & C1; w[3 * q + 2] = perm(e, e, 0x03030302u) & C2;
                     }
-                    u32x4* op3 = (u32x4*)(out + 3 * ((x * H + y) * D + zo));
+                    // A lane's 48 bytes go through a wave-private LDS window and leave in ADDRESS order: the 8 lanes of a row segment hold
+                    // 384 contiguous bytes (three whole lines), so chunk c = 64 k + lane of the wave's 3 KiB belongs to lane c / 3 and every
+                    // store instruction writes whole lines (three stores of 16 bytes every 48 touched each line three times: 1.05 ms).
+                    const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { u32x4 v; v.x = w[4 * k]; v.y = w[4 * k + 1]; v.z = w[4 * k + 2]; v.w = w[4 * k + 3]; op3[k] = v; }   // plain stores: a lane's three pieces interleave with its neighbours' in every line; the L2 merges them (nontemporal: 2.1 ms)
+                    for (int k = 0; k < 3; ++k) { u32x4 v; v.x = w[4 * k]; v.y = w[4 * k + 1]; v.z = w[4 * k + 2]; v.w = w[4 * k + 3]; xch[wv * 192 + 3 * lane + k] = v; }
+                    const i64 mybase = act ? 3 * ((x * H + y) * D + zo) : -1;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int c = 64 * k + lane, L = c / 3, part = c - 3 * L;
+                        const u32x4 v = xch[wv * 192 + c];
+                        const i64 lb = __shfl((long long)mybase, L);
+                        if (lb >= 0) *(u32x4*)(out + lb + 16 * part) = v;
+                    }
                     continue;
                 }
                 if (ALIGNZ) {
