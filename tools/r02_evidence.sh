@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-2 evidence, produced on the GPU box in one go: bench line + rocprofv3 kernel stats + PMC traffic of the same command,
-# every op of SURVEY 8(d), the real shapes, the generic-angle step (time, FETCH/WRITE, SQ counters), the camera objective latency.
+# every op of SURVEY 8(d), the real shapes, the generic-angle step (time, FETCH/WRITE, SQ counters), the camera objective latency,
+# the workgroups-per-CU sweep of the 90-degree kernels, the cold-chain prefetch figures and the notebook-1 chain.
 # usage (from the repo root on the GPU box): bash tools/r02_evidence.sh   -> files under gpurun_out/r02/
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
@@ -17,6 +18,9 @@ python3 tools/m4bench.py --angles 45,30,5,60 --variants 128,256,256:0:0:0:0:0:1 
 python3 tools/m4bench.py --size 512 --angles 45 --variants 64,128,256 --reps 10 > $O/m4bench_512.jsonl 2>&1
 python3 tools/m4bench.py --size 512x278x512 --angles 45 --variants 64,128,256 --reps 10 >> $O/m4bench_512.jsonl 2>&1
 python3 tools/objbench.py > $O/objective_latency.jsonl 2> $O/objbench.err
+python3 tools/tybench.py --fills 0,4,6,8,12 > $O/tybench.jsonl 2> $O/tybench.err
+python3 tools/chainbench.py > $O/chainbench.jsonl 2> $O/chainbench.err
+python3 tools/notebook1_bench.py > $O/notebook1.json 2> $O/notebook1.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/opbench_stats -- python3 $R/tools/opbench.py --ops M3,M4,M5,M6,M7,M8,A9 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/opbench_fetch -- python3 $R/tools/opbench.py --ops M3,M4,M5,M6,M7,M8 --reps 2 > /dev/null 2>&1
