@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256) void k_color_apply_generic(const u8* __restric
 //                  colored[v] itself, so the overlay is the union of the jobs' keep sets)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_part_occ(const u8* __restrict__ colored, const u8* __restrict__ mask_sub,
-                                                  u8* __restrict__ occ, i64 nvox, i64 D) {
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+                                                  u8* __restrict__ occ, i64 nvox, i64 D, i64 v_first = 0) {
+    for (i64 v = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
         const i64 xy = v / D;
         u8 r = 0;
         if (mask_sub[xy]) r = (colored[3 * v] | colored[3 * v + 1] | colored[3 * v + 2]) ? 1 : 0;
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void k_part_occ(const u8* __restrict__ colored
 }
 
 __global__ __launch_bounds__(256) void k_keep_or(const u8* __restrict__ carved, const u8* __restrict__ mask_sub,
-                                                 u8* __restrict__ keep, i64 nvox, i64 D, int first) {
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+                                                 u8* __restrict__ keep, i64 nvox, i64 D, int first, i64 v_first = 0) {
+    for (i64 v = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
         const i64 xy = v / D;
         // part = (colored*m)*carved in uint8: non-zero iff m, carved (0/1 here) and colour non-zero
         const u8 k = (mask_sub[xy] && carved[v]) ? 1 : 0;
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256) void k_keep_or(const u8* __restrict__ carved, 
 }
 
 __global__ __launch_bounds__(256) void k_part_final(const u8* __restrict__ colored, const u8* __restrict__ keep,
-                                                    u8* __restrict__ out, i64 nvox) {
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
+                                                    u8* __restrict__ out, i64 nvox, i64 v_first = 0) {
+    for (i64 v = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
         const bool k = keep[v] != 0;
         out[3 * v] = k ? colored[3 * v] : (u8)0;
         out[3 * v + 1] = k ? colored[3 * v + 1] : (u8)0;
@@ -360,13 +360,25 @@ __global__ __launch_bounds__(256) void k_part_final(const u8* __restrict__ color
     }
 }
 
-// 16-voxel-per-lane forms of the three kernels above (D % 16 == 0, 16-byte aligned buffers): a group of 16 voxels
-// lies in one (x,y) column, so the 2-D mask byte is read once per group and skipped groups cost no grid read.
+// 16-voxel-per-lane forms of the three kernels above (16-byte aligned buffers, D >= 16, fewer than 2^32 voxels): the volume is a
+// flat stream of 16-voxel groups; a group lies in one (x,y) column or -- when D is not a multiple of 16 -- straddles two, so the 2-D
+// mask is read once or twice per group and skipped groups cost no grid read.  The stream's last nvox % 16 voxels go through the
+// scalar kernels (v_first).
+__device__ __forceinline__ u32 group_sel16(const u8* __restrict__ mask_sub, i64 g, const pb3d_magic mD) {
+    const u32 v0 = (u32)(16 * g);
+    const u32 col0 = pb3d_div(v0, mD), nfirst = mD.d - (v0 - col0 * mD.d);          // voxels of the group in its first column
+    u32 sel = mask_sub[col0] ? 0xffffu : 0u;
+    if (nfirst < 16u) { const u32 lowm = (1u << nfirst) - 1u; sel = (sel & lowm) | (mask_sub[col0 + 1] ? (0xffffu & ~lowm) : 0u); }
+    return sel;
+}
+__device__ __forceinline__ u32 spread4(u32 b4) { return ((b4 * 0x00204081u) & 0x01010101u) * 0xffu; }      // bit j -> byte j = 0xff
+
 __global__ __launch_bounds__(256) void k_part_occ16(const u32x4* __restrict__ colored, const u8* __restrict__ mask_sub,
-                                                    u32x4* __restrict__ occ, i64 ngroups, i64 D16) {
+                                                    u32x4* __restrict__ occ, i64 ngroups, pb3d_magic mD) {
     for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
         u32 o[4] = {0, 0, 0, 0};
-        if (mask_sub[g / D16]) {
+        const u32 sel = group_sel16(mask_sub, g, mD);
+        if (sel) {
             u32 w[12];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { const u32x4 t = ld_s(colored + 3 * g + k); w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
@@ -375,6 +387,10 @@ __global__ __launch_bounds__(256) void k_part_occ16(const u32x4* __restrict__ co
                 const u32 any = byte_of(w, 3 * i) | byte_of(w, 3 * i + 1) | byte_of(w, 3 * i + 2);
                 o[i >> 2] |= (any ? 1u : 0u) << ((i & 3) * 8);
             }
+            if (sel != 0xffffu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] &= spread4((sel >> (4 * j)) & 15u);
+            }
         }
         u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
         st_nt(occ + g, r);
@@ -382,10 +398,11 @@ __global__ __launch_bounds__(256) void k_part_occ16(const u32x4* __restrict__ co
 }
 
 __global__ __launch_bounds__(256) void k_keep_or16(const u32x4* __restrict__ carved, const u8* __restrict__ mask_sub,
-                                                   u32x4* __restrict__ keep, i64 ngroups, i64 D16, int first) {
+                                                   u32x4* __restrict__ keep, i64 ngroups, pb3d_magic mD, int first) {
     for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
         u32x4 k = (u32x4)(0u);
-        if (mask_sub[g / D16]) {
+        const u32 sel = group_sel16(mask_sub, g, mD);
+        if (sel) {
             const u32x4 c = carved[g];
             // per byte: non-zero -> 1 (carved is 0/1 on this path, but stay exact for any byte value)
             const u32 cw[4] = {c.x, c.y, c.z, c.w};
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(256) void k_keep_or16(const u32x4* __restrict__ car
             for (int j = 0; j < 4; ++j) {
                 u32 t = cw[j];
                 t |= t >> 4; t |= t >> 2; t |= t >> 1;   // fold every byte's bits into its bit 0
-                kw[j] = t & 0x01010101u;
+                kw[j] = t & 0x01010101u & spread4((sel >> (4 * j)) & 15u);
             }
             k.x = kw[0]; k.y = kw[1]; k.z = kw[2]; k.w = kw[3];
         }
@@ -431,8 +448,9 @@ __global__ __launch_bounds__(256) void k_part_final16(const u32x4* __restrict__ 
 }
 
 // out[v] = colored[v] where keep[v] (the rest of `out` -- the overlay of the fused 90-degree jobs -- stays)
-__global__ __launch_bounds__(256) void k_part_merge(const u8* __restrict__ colored, const u8* __restrict__ keep, u8* __restrict__ out, i64 nvox) {
-    for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x)
+__global__ __launch_bounds__(256) void k_part_merge(const u8* __restrict__ colored, const u8* __restrict__ keep, u8* __restrict__ out, i64 nvox,
+                                                    i64 v_first = 0) {
+    for (i64 v = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x)
         if (keep[v]) { out[3 * v] = colored[3 * v]; out[3 * v + 1] = colored[3 * v + 1]; out[3 * v + 2] = colored[3 * v + 2]; }
 }
 
@@ -574,8 +592,9 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)nvox, &keep));
     const unsigned blocks = pb3d_stream_blocks(ctx, nvox, 256, 8);
-    const bool wide = (D % 16 == 0) && aligned16(d_colored) && aligned16(d_out);   // scratch buffers are 4 KiB aligned
-    const i64 ngroups = nvox / 16;
+    const bool wide = D >= 16 && nvox < (1ll << 32) && aligned16(d_colored) && aligned16(d_out);   // scratch buffers are 4 KiB aligned
+    const i64 ngroups = nvox / 16, vtail = 16 * ngroups;                    // the last nvox % 16 voxels: scalar kernels from vtail on
+    const pb3d_magic mD = pb3d_make_magic((u32)(D > 0 ? D : 1));
     const unsigned gblocks = pb3d_stream_blocks(ctx, ngroups > 0 ? ngroups : 1, 256, 8);
     bool any = false;
     for (int j = 0; j < njobs; ++j) {
@@ -583,18 +602,19 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         const u8* ms = d_mask_sub + (i64)j * W * H;
         const u8* mc = d_mask_carve + (i64)j * W * H;
         PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));          // tables of the job's first rotation, behind the kernels below
-        if (wide)
-            hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, D / 16);
-        else
+        if (wide) {
+            hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, mD);
+            if (vtail < nvox) hipLaunchKernelGGL(k_part_occ, dim3(1), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D, vtail);
+        } else
             hipLaunchKernelGGL(k_part_occ, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D);
         PB3D_CHECK_LAUNCH();
         PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
         for (int jn = j + 1; jn < njobs; ++jn)                                  // ... and of the next job's, behind this job's last kernels
             if (!job_skip[jn]) { PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jn])); break; }
-        if (wide)
-            hipLaunchKernelGGL(k_keep_or16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)carved, ms, (u32x4*)keep, ngroups, D / 16,
-                               any ? 0 : 1);
-        else
+        if (wide) {
+            hipLaunchKernelGGL(k_keep_or16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)carved, ms, (u32x4*)keep, ngroups, mD, any ? 0 : 1);
+            if (vtail < nvox) hipLaunchKernelGGL(k_keep_or, dim3(1), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, vtail);
+        } else
             hipLaunchKernelGGL(k_keep_or, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1);
         PB3D_CHECK_LAUNCH();
         any = true;
@@ -604,18 +624,20 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         return PB3D_OK;
     }
     if (base90) {
-        if (wide)
+        if (wide) {
             hipLaunchKernelGGL(k_part_merge16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, (const u32x4*)keep, (u32x4*)d_out,
                                ngroups);
-        else
+            if (vtail < nvox) hipLaunchKernelGGL(k_part_merge, dim3(1), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox, vtail);
+        } else
             hipLaunchKernelGGL(k_part_merge, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }
-    if (wide)
+    if (wide) {
         hipLaunchKernelGGL(k_part_final16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, (const u32x4*)keep, (u32x4*)d_out,
                            ngroups);
-    else
+        if (vtail < nvox) hipLaunchKernelGGL(k_part_final, dim3(1), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox, vtail);
+    } else
         hipLaunchKernelGGL(k_part_final, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, (const u8*)keep, d_out, nvox);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;

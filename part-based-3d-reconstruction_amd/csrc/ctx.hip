@@ -174,7 +174,8 @@ int pb3d_dev_alloc(pb3d_ctx* ctx, size_t bytes, void** dptr) {
     *dptr = nullptr;
     PB3D_HIP(hipSetDevice(ctx->device));
     // round up so that 16-byte vector tails never leave the allocation
-    size_t padded = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    // (+ 64: kernels that read whole 16-byte units may run up to 15 bytes past a volume whose rows are not multiples of 16)
+    size_t padded = ((bytes ? bytes : 1) + 64 + 255) & ~(size_t)255;
     // best fit among the cached blocks: at least the request, at most an eighth (+ 1 MiB) more
     int best = -1;
     for (int i = 0; i < ctx->pool_nfree; ++i) {
@@ -329,7 +330,7 @@ int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
             ctx->scratch[slot] = nullptr;
             ctx->scratch_bytes[slot] = 0;
         }
-        size_t padded = ((bytes ? bytes : 1) + 4095) & ~(size_t)4095;
+        size_t padded = ((bytes ? bytes : 1) + 64 + 4095) & ~(size_t)4095;
         PB3D_HIP(pool_malloc(ctx, &ctx->scratch[slot], padded));
         ctx->scratch_bytes[slot] = padded;
         ++ctx->scratch_gen;

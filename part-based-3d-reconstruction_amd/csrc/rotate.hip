@@ -1081,20 +1081,21 @@ __global__ __launch_bounds__(PTHREADS) void k_rot8_tiles(const PPart* __restrict
 // kernel (device-side flag).
 struct RunRec { u32 w0, w1, w2, w3; };
 
-// one lane per cell, 16 consecutive lanes per run
-__global__ __launch_bounds__(256) void k_rot8_pack(const CellRec* __restrict__ cells, PTile* __restrict__ tiles, i64 W, i64 D, int ntz,
+// one lane per cell, 16 consecutive lanes per run; a row has nruns = ceil(D / 16) runs, the cells of the last one past D are void
+__global__ __launch_bounds__(256) void k_rot8_pack(const CellRec* __restrict__ cells, PTile* __restrict__ tiles, i64 W, i64 D, int ntz, int nruns,
                                                    RunRec* __restrict__ runs) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;       // cell index x * D + z (D % 16 == 0: a run never straddles rows)
-    const bool inside = i < W * D;
-    const i64 x = inside ? i / D : 0, z = inside ? i - x * D : 0;
-    PTile* ti = tiles + (x / PT) * ntz + z / PT;
+    const i64 gr = (i64)blockIdx.x * 16 + (threadIdx.x >> 4);       // run index x * nruns + rz
     const int c = (int)(threadIdx.x & 15);                          // position in the run
-    const bool tile_ok = inside && ti->fits;
+    const bool inside = gr < W * nruns;
+    const i64 x = inside ? gr / nruns : 0, z = inside ? 16 * (gr - x * nruns) + c : 0;
+    const bool cell = inside && z < D;
+    PTile* ti = tiles + (x / PT) * ntz + (cell ? z : 0) / PT;
+    const bool tile_ok = cell && ti->fits;
     bool live = false, bad = false;
     int r = 0, s2 = 0;
     u32 k = 15;
     if (tile_ok) {
-        const CellRec cr = cells[i];
+        const CellRec cr = cells[x * D + z];
         if (cr.src != 0xffffffffu) {
             live = true;
             r = (int)(cr.src >> 16) - ti->bx0;
@@ -1125,8 +1126,8 @@ __global__ __launch_bounds__(256) void k_rot8_pack(const CellRec* __restrict__ c
         w0 |= (u32)__shfl_xor((int)w0, o); w1 |= (u32)__shfl_xor((int)w1, o);
         w2 |= (u32)__shfl_xor((int)w2, o); w3 |= (u32)__shfl_xor((int)w3, o);
     }
-    if (__ballot(bad) && bad) ti->fits = 0;                         // benign race: every writer stores 0
-    if (inside && c == 0) { RunRec rec = {w0, w1, w2, w3}; runs[i >> 4] = rec; }
+    if (bad) ti->fits = 0;                                          // benign race: every writer stores 0
+    if (inside && c == 0) { RunRec rec = {w0, w1, w2, w3}; runs[gr] = rec; }
 }
 
 __device__ __forceinline__ u32 lut_apply14(u32 lut14, u32 t00, u32 t01, u32 t10, u32 t11) {
@@ -1162,11 +1163,16 @@ __device__ __forceinline__ u32 mask8(const u8* __restrict__ p, int np) {
 // 512 threads, two workgroups per CU (verified resident together: tools/kbench5.hip).  Tried and measured no better: one 1024-thread
 // workgroup whose two wave groups alternate stage / evaluate by construction, random start staggers, and a skewed cyclic walk of
 // the runs against LDS bank conflicts -- none of them moved the time, because the kernel was bound by VALU ISSUE (below).
-template <bool SRCMASK>
+// ODD: D % 16 != 0 (the reference's real shapes: 355, 437 ...).  Source units and output runs are then 16 bytes at arbitrary byte
+// addresses (gfx950 serves those at full speed), the last run of an output row is stored byte-wise up to D, and the last unit of a
+// source row reads up to 15 bytes past the row -- the next row's voxels, which no tap addresses; the launcher takes this path only
+// when the input ALLOCATION extends 16 bytes past the volume (hipMemGetAddressRange; the library's own buffers always do).
+template <bool SRCMASK, bool ODD>
 __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
                                                                const RunRec* __restrict__ runs, const PTile* __restrict__ tiles, i64 W, i64 H, i64 D,
                                                                int TY, int ntz, int ntiles, int nchunks, int* __restrict__ big_flag,
-                                                               const u8* __restrict__ mask_src, int abl) {
+                                                               const u8* __restrict__ mask_src, int abl, int nruns) {
+    typedef u32 u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
     extern __shared__ __attribute__((aligned(16))) u8 plds[];
     int* atab = (int*)(plds + PLDS_DATA);              // PROWS + 1 entries
     u32* dict = (u32*)(atab + PROWS + 1);              // 16 entries
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
     for (int k = 0; k < 8; ++k) {
         const i64 x = x0 + 32 * k + (tid >> 4), z = z0 + zc;
         run[k] = u32x4{0u, 0u, 0xffffffffu, 0xffffffffu};          // outside the grid: 16 void cells at the footprint origin
-        if (x < W && z < D) run[k] = *(const u32x4*)(runs + x * (D / 16) + (z >> 4));
+        if (x < W && z < D) run[k] = *(const u32x4*)(runs + x * nruns + (z >> 4));
     }
     __syncthreads();
     // dictionary entry e as the kernel wants it: table bits 1..7 in byte 0, bits 8..14 in byte 1, table bit 15 (= 1 for every real
@@ -1231,7 +1237,7 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int qe = q0 + q < np ? q0 + q : np - 1;     // uniform
-                dd[q] = *(const u32x4*)(in + (yg + qe) * D + voff);
+                dd[q] = ODD ? (u32x4)*(const u32x4a1*)(in + (yg + qe) * D + voff) : *(const u32x4*)(in + (yg + qe) * D + voff);
             }
         };
         load_half(d[0], 0);
@@ -1265,6 +1271,13 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
 #pragma unroll 1
         for (int qq = 0; qq < 8; ++qq) {
             if (abl & 1) break;
+            if (x0 + 32 * qq + 4 * (tid >> 6) >= W) {          // all four x-rows of this wave's slot are past the grid (edge tiles)
+                const u32x4 t0 = run[0];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) run[k] = run[k + 1];
+                run[7] = t0;
+                continue;
+            }
             // Four cells at a time (rolled loop, one group's registers live): positions by the run's step bits, one row-table read
             // pair and one dictionary read per cell, 16 tap bytes -- then the taps of the four cells are packed bytewise into four
             // dwords and SciPy's table is applied to all four cells x 8 planes at once: mask L_k has byte c = 0xff where cell c's
@@ -1325,7 +1338,14 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
                     if (q >= np) break;
                     u32x4 rr;
                     rr.x = (A0 >> q) & 0x01010101u; rr.y = (A1 >> q) & 0x01010101u; rr.z = (A2 >> q) & 0x01010101u; rr.w = (A3 >> q) & 0x01010101u;
-                    *(u32x4*)(out + (yg + q) * D + ooff) = rr;
+                    u8* op = out + (yg + q) * D + ooff;
+                    if (!ODD) *(u32x4*)op = rr;
+                    else if (z + 16 <= D) *(u32x4a1*)op = rr;
+                    else {                                                              // the row's last run: its own bytes only
+                        const u32 t4[4] = {rr.x, rr.y, rr.z, rr.w};
+                        const int nb = (int)(D - z);
+                        for (int b = 0; b < nb; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+                    }
                 }
             }
             const u32x4 t0 = run[0];
@@ -1466,10 +1486,19 @@ static const int kSetSlots[2][5] = {{16, 20, 17, 18, 19}, {26, 27, 28, 29, 30}};
 
 // which tile kernel a table-driven step uses: 1 packed 256-tiles, 2 wide 128-tiles, 3 64-tiles (the parity tests pin each of them on
 // the same grids: ctx->tune_rotate_tile = 64 / 128 / 256)
-static int table_kind(const pb3d_ctx* ctx, i64 W, i64 H, i64 D) {
+// does the allocation that holds [p, p + bytes) extend at least 16 bytes further?  (one driver query; false when in doubt)
+static bool has_read_slack(const void* p, size_t bytes) {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return (const char*)p + bytes + 16 <= (const char*)base + size;
+}
+
+// odd_ok: rows that are not multiples of 16 bytes may take the packed kernel (the input allocation has 16 bytes of slack)
+static int table_kind(const pb3d_ctx* ctx, i64 W, i64 H, i64 D, bool odd_ok) {
     const int pin = ctx->tune_rotate_tile;
     const i64 ptiles = ((D + PT - 1) / PT) * ((W + PT - 1) / PT);
-    const bool packed_ok = D % 16 == 0 && W * H * D < (1ll << 32) - 64 && H >= 8;
+    const bool packed_ok = (D % 16 == 0 || (odd_ok && D >= 16)) && W * H * D < (1ll << 32) - 64 && H >= 8;
     // measured (tools/m4bench.py, 45 degrees): 512^3 0.061 ms against 0.113 (64-tiles) / 0.139 (128-tiles); 512 x 278 x 512 0.053 / 0.070 / 0.125
     if (packed_ok && (pin ? pin == 256 : (W >= 256 && D >= 256 && ptiles * ((H + 7) / 8) >= 64))) return 1;
     const i64 xtiles = ((D + XT - 1) / XT) * ((W + XT - 1) / XT);
@@ -1504,7 +1533,7 @@ static int packed_alloc(pb3d_ctx* ctx, int k, i64 W, i64 D, TableSet* t) {
     PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][1], 512 * sizeof(u32), &t->lutmap));
     PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][2], (size_t)ptiles * PPARTS * sizeof(PPart), &t->parts));
     PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][3], (size_t)ptiles * sizeof(PTile), &t->tinfo));
-    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][4], (size_t)(W * (D / 16)) * sizeof(RunRec), &t->runs));
+    PB3D_TRY(pb3d_scratch(ctx, kSetSlots[k][4], (size_t)(W * ((D + 15) / 16)) * sizeof(RunRec), &t->runs));
     return PB3D_OK;
 }
 // cells -> tile parts -> tile footprints -> run records of a packed step, queued on `st`
@@ -1515,7 +1544,8 @@ static int packed_build(pb3d_ctx* ctx, hipStream_t st, const TableSet& t, const 
     hipLaunchKernelGGL(k_rot_cells, dim3((unsigned)((W * D + 1023) / 1024)), dim3(256), 0, st, p, W, D, (CellRec*)t.cells, (u32*)t.lutmap);
     hipLaunchKernelGGL(k_rot8_parts, dim3((unsigned)(ptiles * PPARTS)), dim3(PTHREADS), 0, st, (const CellRec*)t.cells, W, D, ntz, (PPart*)t.parts);
     hipLaunchKernelGGL(k_rot8_tiles, dim3((unsigned)ptiles), dim3(PTHREADS), 0, st, (const PPart*)t.parts, (const u32*)t.lutmap, H, D, (PTile*)t.tinfo);
-    hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * D + 255) / 256)), dim3(256), 0, st, (const CellRec*)t.cells, (PTile*)t.tinfo, W, D, ntz,
+    const int nruns = (int)((D + 15) / 16);
+    hipLaunchKernelGGL(k_rot8_pack, dim3((unsigned)((W * nruns + 15) / 16)), dim3(256), 0, st, (const CellRec*)t.cells, (PTile*)t.tinfo, W, D, ntz, nruns,
                        (RunRec*)t.runs);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
@@ -1533,7 +1563,8 @@ static bool generic_step_is_tiled(const double M[9], i64 W, i64 H, i64 D) {
 // is not a packed table step or its tables are already there.
 int pb3d_prefetch_rotation(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3]) {
     if (ctx->tune_misc[4] != 0 || W * H * D == 0) return PB3D_OK;                              // misc4 = 1: no reuse, 2: no prefetch
-    if (!generic_step_is_tiled(M, W, H, D) || !table_step_takes_src_mask(W, H, D) || table_kind(ctx, W, H, D) != 1) return PB3D_OK;
+    // (odd D: the tables are built for the packed kernel; a step whose input turns out to have no read slack simply does not use them)
+    if (!generic_step_is_tiled(M, W, H, D) || !table_step_takes_src_mask(W, H, D) || table_kind(ctx, W, H, D, true) != 1) return PB3D_OK;
     const RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     for (int k = 0; k < 2; ++k)
         if (cache_hit(ctx, ctx->rot_cache[k], 1, p, W, H, D)) return PB3D_OK;
@@ -1572,12 +1603,15 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
     // part_carve jobs with one angle, the same process_voxel_grid on grid after grid -- finds them where an earlier call left them
     // (two sets of private scratch slots; the stream is in order); a chain of different steps finds them where
     // pb3d_prefetch_rotation built them meanwhile.  tune misc4 = 1 switches the reuse off, 2 the prefetch.
-    const int kind = table_kind(ctx, W, H, D);
+    const bool odd = D % 16 != 0;
+    const int kind = table_kind(ctx, W, H, D, odd && ctx->tune_misc[5] != 3 && has_read_slack(d_in, (size_t)(W * H * D)));
     const bool packed = kind == 1, wide = kind == 2;
     if (packed) {
         if (!ctx->packed_lds_set) {
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
-            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_rotate_bits8p<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPLds));
             ctx->packed_lds_set = true;
         }
         int k = -1;
@@ -1598,9 +1632,10 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         const int nchunks = (int)((H + TYP - 1) / TYP);
         const i64 nblk = 8 * ptiles * ((nchunks + 7) / 8);
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
-        auto kern = d_mask_src ? k_rotate_bits8p<true> : k_rotate_bits8p<false>;
+        auto kern = odd ? (d_mask_src ? k_rotate_bits8p<true, true> : k_rotate_bits8p<false, true>)
+                        : (d_mask_src ? k_rotate_bits8p<true, false> : k_rotate_bits8p<false, false>);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)t.runs,
-                           (const PTile*)t.tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0]);
+                           (const PTile*)t.tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0], (int)((D + 15) / 16));
         PB3D_CHECK_LAUNCH();
         cache_set(ctx, rc, 1, p, W, H, D, t.cells);
         PB3D_TRY(mark_used(ctx, k));

@@ -574,8 +574,9 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
     # (133,121,129): the same kernel with rows at arbitrary byte alignment and ragged row ends; (400,20,272) / (300,20,357):
     # fewer than 32 planes -> 8-plane kernel, aligned and byte-wise forms
     # (271,33,240): D % 16 == 0 but D % 32 != 0 -- the wide kernel's 32-voxel runs straddle the row end (found by tools/fuzz_gpu.py)
+    # (355,16,355) / (290,40,333): odd rows through the packed kernel's byte-aligned form (two x-tiles, edge slots skipped, last runs partial)
     for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130), (133, 121, 129), (300, 20, 357),
-                      (271, 33, 240)]:
+                      (271, 33, 240), (355, 16, 355), (290, 40, 333)]:
         m = rng.random((H, W)) < 0.9
         g_bin = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         g_full = rng.integers(0, 256, (W, H, D), dtype=np.uint8)
@@ -583,8 +584,8 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
         for ai in (45, 30, 50):
             for g in (g_bin, g_full, g_one_big):
                 want = oracle.process_voxel_grid(g, m, ai)
-                # the 64x64 / 32-plane, the 128x128 / 16-plane and (D % 16 == 0) the packed 256x256 / 8-plane kernels; the
-                # library picks by size
+                # the 64x64 / 32-plane, the 128x128 / 16-plane and the packed 256x256 / 8-plane kernels (any D: rows that are not
+                # multiples of 16 bytes take its byte-aligned form); the library picks by size
                 for tile in (64, 128, 256):
                     pb3d_gpu._lib.set_tuning("rotate_tile", tile)
                     try:
