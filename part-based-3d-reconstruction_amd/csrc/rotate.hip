@@ -1171,14 +1171,18 @@ template <bool SRCMASK, bool ODD>
 __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_wh,
                                                                const RunRec* __restrict__ runs, const PTile* __restrict__ tiles, i64 W, i64 H, i64 D,
                                                                int TY, int ntz, int ntiles, int nchunks, int* __restrict__ big_flag,
-                                                               const u8* __restrict__ mask_src, int abl, int nruns) {
+                                                               const u8* __restrict__ mask_src, int abl, int nruns, int nsplit) {
     typedef u32 u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
     extern __shared__ __attribute__((aligned(16))) u8 plds[];
     int* atab = (int*)(plds + PLDS_DATA);              // PROWS + 1 entries
     u32* dict = (u32*)(atab + PROWS + 1);              // 16 entries
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
-    const int slot = (int)(blockIdx.x >> 3);
+    // nsplit = 2 / 4 (grids whose tiles x plane chunks do not fill the chip): that many workgroups share a (tile, chunk); each stages
+    // the whole footprint and evaluates 8 / nsplit of the run slots.  They follow each other on one XCD, so the footprint comes out of
+    // its L2 for all but the first.
+    const int slot2 = (int)(blockIdx.x >> 3);
+    const int sub = slot2 % nsplit, slot = slot2 / nsplit;
     const int t = slot % ntiles;
     const int chunk = (slot / ntiles) * 8 + (int)(blockIdx.x & 7u);
     if (chunk >= nchunks) return;                      // whole workgroup, before any barrier
@@ -1271,7 +1275,7 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
 #pragma unroll 1
         for (int qq = 0; qq < 8; ++qq) {
             if (abl & 1) break;
-            if (x0 + 32 * qq + 4 * (tid >> 6) >= W) {          // all four x-rows of this wave's slot are past the grid (edge tiles)
+            if (x0 + 32 * qq + 4 * (tid >> 6) >= W || (qq * nsplit) / 8 != sub) {     // all four x-rows of this wave's slot are past the grid (edge tiles), or the slot is another workgroup's
                 const u32x4 t0 = run[0];
 #pragma unroll
                 for (int k = 0; k < 7; ++k) run[k] = run[k + 1];
@@ -1630,12 +1634,16 @@ static int launch_table_step(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D,
         // the more workgroups, the better their stage and evaluate phases interleave across the chip)
         int TYP = ctx->tune_rot8_ty > 0 ? ctx->tune_rot8_ty : 8;
         const int nchunks = (int)((H + TYP - 1) / TYP);
-        const i64 nblk = 8 * ptiles * ((nchunks + 7) / 8);
+        // fewer (tile, chunk) pairs than two per CU: split the run slots of a pair over 2 or 4 workgroups (tune misc5 = 4: never)
+        int nsplit = 1;
+        if (ctx->tune_misc[5] != 4)
+            while (nsplit < 4 && ptiles * nchunks * nsplit * 2 <= (i64)ctx->cus * 2) nsplit *= 2;
+        const i64 nblk = 8 * ptiles * nsplit * ((nchunks + 7) / 8);
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_rotate_carve: grid too large");
         auto kern = odd ? (d_mask_src ? k_rotate_bits8p<true, true> : k_rotate_bits8p<false, true>)
                         : (d_mask_src ? k_rotate_bits8p<true, false> : k_rotate_bits8p<false, false>);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(PTHREADS), kPLds, ctx->stream, d_in, d_out, d_mask_wh, (const RunRec*)t.runs,
-                           (const PTile*)t.tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0], (int)((D + 15) / 16));
+                           (const PTile*)t.tinfo, W, H, D, TYP, ntz, (int)ptiles, nchunks, flag, d_mask_src, ctx->tune_misc[0], (int)((D + 15) / 16), nsplit);
         PB3D_CHECK_LAUNCH();
         cache_set(ctx, rc, 1, p, W, H, D, t.cells);
         PB3D_TRY(mark_used(ctx, k));
@@ -1752,7 +1760,7 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     const unsigned gx = (unsigned)((D + 255) / 256), gy = (unsigned)((W + 3) / 4), gz = (unsigned)((H + TY - 1) / TY);
     const u64 nblk = (u64)gx * gy * gz;
     // after a table-driven step this launch normally only reads the flag: a few workgroups per CU walk the block space if it runs
-    const u64 cap = tiled ? (u64)ctx->cus * 8 : 0x7fffffffull;
+    const u64 cap = tiled ? (u64)ctx->cus * 4 : 0x7fffffffull;
     const unsigned launch = (unsigned)(nblk < cap ? nblk : cap);
     const bool pack = (D % 4 == 0) && (((uintptr_t)d_out & 3u) == 0);
     if (pack)
