@@ -69,6 +69,8 @@ struct pb3d_ctx {
         bool used_valid;
     } rot_cache[2];
     u64 rot_stamp;
+    void* flag_ring;            // the ring of "value > 1 seen" flag words of the generic-angle steps (scratch slot 15) and its position
+    u64 flag_gen;
     hipStream_t aux_stream;     // table builds that overlap the main stream's kernels
     // Device block pool behind pb3d_dev_alloc / pb3d_dev_free: a freed block is kept (no hipFree, no stream synchronisation) and handed
     // to the next request of about its size.  Everything that touches such a block runs on ctx->stream, in order, so a re-used block

@@ -81,7 +81,8 @@ template <bool PACK>
 __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ in, u8* __restrict__ out,
                                                         const u8* __restrict__ mask_wh, RotParams p, i64 W, i64 H, i64 D,
                                                         int TY, const int* __restrict__ run_if, const u8* __restrict__ mask_src,
-                                                        unsigned gx, unsigned gy, unsigned gz) {
+                                                        unsigned gx, unsigned gy, unsigned gz, int* __restrict__ clear_flag = nullptr) {
+    if (clear_flag && blockIdx.x == 0 && threadIdx.x == 0) *clear_flag = 0;      // the flag word of a LATER step (ring of 16, see the launcher)
     if (run_if && *run_if == 0) return;   // second pass of a table-driven step: only when a value > 1 was seen
     // the (gx, gy, gz) block space is walked by however many workgroups were launched: the conditional second pass is launched
     // with a small grid, so that skipping it costs microseconds
@@ -1745,12 +1746,17 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     // the arithmetic kernel alone.  The footprint of a 64 x 64 tile must fit the LDS box: true for
     // rotations (row sums of |M| <= sqrt 2).
     const bool tiled = generic_step_is_tiled(M, W, H, D);
-    int* flag = nullptr;
+    int *flag = nullptr, *flag_clear = nullptr;
     if (tiled) {
         void* f;
         PB3D_TRY(pb3d_scratch(ctx, 15, 64, &f));
-        flag = (int*)f;
-        PB3D_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+        // The "a value > 1 was seen" flag of step g is word g % 16 of a ring; the conditional second pass of step g clears the word
+        // of step g + 8 (no kernel in flight uses it: the stream is in order), so a step needs no memset of its own.  The ring is
+        // zeroed when the slot is new (another user of the slot may have grown it).
+        if (ctx->flag_ring != f) { PB3D_HIP(hipMemsetAsync(f, 0, 64, ctx->stream)); ctx->flag_ring = f; ctx->flag_gen = 0; }
+        flag = (int*)f + (ctx->flag_gen & 15);
+        flag_clear = (int*)f + ((ctx->flag_gen + 8) & 15);
+        ++ctx->flag_gen;
         PB3D_TRY(launch_table_step(ctx, d_in, W, H, D, p, d_mask_wh, d_out, flag, d_mask_src));
     }
     int TY = tiled ? 64 : 16;      // after a table-driven step the grid only reads the flag: keep that launch small
@@ -1764,9 +1770,9 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     const unsigned launch = (unsigned)(nblk < cap ? nblk : cap);
     const bool pack = (D % 4 == 0) && (((uintptr_t)d_out & 3u) == 0);
     if (pack)
-        hipLaunchKernelGGL(k_rotate_generic<true>, dim3(launch), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src, gx, gy, gz);
+        hipLaunchKernelGGL(k_rotate_generic<true>, dim3(launch), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src, gx, gy, gz, flag_clear);
     else
-        hipLaunchKernelGGL(k_rotate_generic<false>, dim3(launch), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src, gx, gy, gz);
+        hipLaunchKernelGGL(k_rotate_generic<false>, dim3(launch), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_wh, p, W, H, D, TY, flag, d_mask_src, gx, gy, gz, flag_clear);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
