@@ -69,6 +69,7 @@ struct pb3d_ctx {
         bool used_valid;
     } rot_cache[2];
     u64 rot_stamp;
+    struct ValidCache { void* buf; u64 gen; i64 W, D; double p[8]; } valid_cache;   // validity bit table of the last 90-degree step (scratch slot 10)
     void* flag_ring;            // the ring of "value > 1 seen" flag words of the generic-angle steps (scratch slot 15) and its position
     u64 flag_gen;
     hipStream_t aux_stream;     // table builds that overlap the main stream's kernels

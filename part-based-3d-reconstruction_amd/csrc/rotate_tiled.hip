@@ -1094,10 +1094,21 @@ static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u3
     const int n = (int)(((D + 63) / 64) * 2 + 2);
     void* buf;
     PB3D_TRY(pb3d_scratch(ctx, 10, (size_t)W * n * sizeof(u32), &buf));
+    // the table depends on (matrix, offset, W, D) only and slot 10 is private to it: a repeated step (every 90-degree call on one shape)
+    // finds it in place -- at 512-class sizes the memset + table kernel were 10 % of a process_voxel_grid(., ., 90) call
+    pb3d_ctx::ValidCache& vc = ctx->valid_cache;
+    if (vc.buf == buf && vc.gen == ctx->scratch_gen && vc.W == W && vc.D == D && memcmp(vc.p, &p, sizeof(RotParams)) == 0 && ctx->tune_misc[4] != 1) {
+        *bits = (u32*)buf; *nw = n;
+        return PB3D_OK;
+    }
+    vc.buf = nullptr;
     PB3D_HIP(hipMemsetAsync(buf, 0, (size_t)W * n * sizeof(u32), ctx->stream));
     dim3 grid((unsigned)((D + 255) / 256), (unsigned)W);
     hipLaunchKernelGGL(k_rot_valid, grid, dim3(256), 0, ctx->stream, p, W, D, n, (u32*)buf);
     PB3D_CHECK_LAUNCH();
+    vc.buf = buf; vc.gen = ctx->scratch_gen; vc.W = W; vc.D = D;
+    static_assert(sizeof(vc.p) == sizeof(RotParams), "ValidCache holds one RotParams");
+    memcpy(vc.p, &p, sizeof(RotParams));
     *bits = (u32*)buf; *nw = n;
     return PB3D_OK;
 }
