@@ -24,6 +24,7 @@ struct SelParams {
     // exact u32 division by A2 and by A1 (Granlund-Montgomery round-up form): q = (t + ((n - t) >> s1)) >> s2, t = mulhi(m, n)
     u32 m2, m1;
     int s2a, s2b, s1a, s1b;
+    int packed;        // 1: (a2, a1, a0) of a voxel fit 21 bits each (k_points_fill16 keeps per-group coordinates as one u64)
 };
 
 struct Magic { u32 m; int sa, sb; };
@@ -293,16 +294,23 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
                                                        float* __restrict__ pts, u8* __restrict__ cols, ScanState st,
                                                        const unsigned short* __restrict__ masks) {
     __shared__ u32 wsum[4];
-    __shared__ u32 htab[256];
+    __shared__ u32 htab[SINGLE ? 256 : 1];              // the two-pass form takes the selection from the count pass's masks
     __shared__ unsigned short lidx[kBlockVox];
-    __shared__ u32 lrec[kBlockVox + 1];
+    __shared__ __attribute__((aligned(16))) u32 lrec[kBlockVox + 8];
+    __shared__ unsigned long long gcoord[64];           // (a2 | a1 << 21 | a0 << 42) of the first voxel of every 64-voxel group of the block (512 bytes: a 2 KB table cost a workgroup per CU)
     __shared__ i64 sh_excl;
-    htab[threadIdx.x] = p.htab[threadIdx.x];
-    __syncthreads();
+    if (SINGLE) { htab[threadIdx.x] = p.htab[threadIdx.x]; __syncthreads(); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u32 bid = blockIdx.x;
     const i64 base = (i64)bid * kBlockVox;
     const i64 v0 = base + 16 * threadIdx.x;
+    // coordinates of a point = its group's first voxel + the position in the group (one pair of divisions per GROUP, not per point)
+    const bool packed_coords = p.packed != 0;             // decided on the host (make_params): every axis < 2^21, A2 >= 64, fewer than 2^32 voxels
+    if (packed_coords && (threadIdx.x & 3) == 0) {
+        const u32 r = magic_div((u32)v0, p.m2, p.s2a, p.s2b), g2 = (u32)v0 - r * (u32)p.A2;
+        const u32 q = magic_div(r, p.m1, p.s1a, p.s1b), g1 = r - q * (u32)p.A1;
+        gcoord[threadIdx.x >> 2] = (unsigned long long)g2 | ((unsigned long long)g1 << 21) | ((unsigned long long)q << 42);
+    }
     u32 w[12];
     u32 bits;
     if (SINGLE) bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
@@ -314,8 +322,13 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
                 const u32x4v* g = (const u32x4v*)(grid + (C == 3 ? 3 : 1) * v0);
 #pragma unroll
                 for (int q = 0; q < (C == 3 ? 3 : 1); ++q) { const u32x4v t = g[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
-            } else {
-                (void)(C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w));   // the grid's ragged end: bounds-checked loads
+            } else {                                    // the grid's ragged end: bounds-checked byte loads
+#pragma unroll
+                for (int k2 = 0; k2 < (C == 3 ? 12 : 4); ++k2) {
+                    u32 t = 0;
+                    for (int b = 0; b < 4; ++b) { const i64 o = (C == 3 ? 3 : 1) * v0 + 4 * k2 + b; if (o < (C == 3 ? 3 : 1) * p.nlat) t |= (u32)grid[o] << (8 * b); }
+                    w[k2] = t;
+                }
             }
         }
     }
@@ -421,13 +434,21 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
         float* gfirst = pts + 3 * (out0 + c0);                          // first float of this chunk
         const u32 shift = (u32)(((uintptr_t)gfirst >> 2) & 3u);          // floats past a 16-byte boundary
         for (u32 q = threadIdx.x; q < nc; q += 256) {
-            const u32 x = b2 + lidx[c0 + q];                            // < A2 + 4096
-            const u32 q2 = magic_div(x, p.m2, p.s2a, p.s2b);
-            const u32 a2 = x - q2 * (u32)p.A2;
-            const u32 y = b1 + q2;                                      // < A1 + 4096
-            const u32 q1 = magic_div(y, p.m1, p.s1a, p.s1b);
-            const u32 a1 = y - q1 * (u32)p.A1;
-            const i64 a0 = b0 + q1;
+            const u32 li = lidx[c0 + q];
+            u32 a2, a1; i64 a0;
+            if (packed_coords) {
+                const unsigned long long gc = gcoord[li >> 6];
+                a2 = ((u32)gc & 0x1fffffu) + (li & 63u); a1 = (u32)(gc >> 21) & 0x1fffffu; a0 = (i64)(gc >> 42);
+                if (a2 >= (u32)p.A2) { a2 -= (u32)p.A2; if (++a1 >= (u32)p.A1) { a1 = 0; ++a0; } }      // the group runs over a row end (A2 >= 64: once)
+            } else {
+                const u32 x = b2 + li;                                  // < A2 + 4096
+                const u32 q2 = magic_div(x, p.m2, p.s2a, p.s2b);
+                a2 = x - q2 * (u32)p.A2;
+                const u32 y = b1 + q2;                                  // < A1 + 4096
+                const u32 q1 = magic_div(y, p.m1, p.s1a, p.s1b);
+                a1 = y - q1 * (u32)p.A1;
+                a0 = b0 + q1;
+            }
             float* l = lp + shift + 3 * q;
             l[0] = (float)a2; l[1] = (float)a1; l[2] = (float)a0;
         }
@@ -453,12 +474,30 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     if (threadIdx.x < hb) co[threadIdx.x] = stream_byte(threadIdx.x);
     const u32 ndw = (nbytes - hb) / 4;
     u32* cw = (u32*)(co + hb);
-    for (u32 d = threadIdx.x; d < ndw; d += 256) {
-        const u32 q = hb + 4 * d;                                   // first stream byte of this dword
-        if (C == 1) { cw[d] = lrec[q] | (lrec[q + 1] << 8) | (lrec[q + 2] << 16) | (lrec[q + 3] << 24); continue; }
-        const u32 r = (q * 43691u) >> 17, ph = q - 3 * r;           // q / 3 exactly (q < 2^16)
-        const unsigned long long two = (unsigned long long)lrec[r] | ((unsigned long long)lrec[r + 1] << 24);
-        cw[d] = (u32)(two >> (8 * ph));
+    if (C == 3) {
+        // three dwords = four records at a time: stream bytes hb + 12 g ... start in record r0 = g * 4 + hb / 3 at phase ph = hb % 3 (the
+        // same for every group of the block); the 24-bit records are strung into dwords W0..W3 and cut at the phase with v_alignbyte
+        const u32 r00 = hb / 3, ph = hb - 3 * r00;
+        const u32 ng = ndw / 3;
+        for (u32 g = threadIdx.x; g < ng; g += 256) {
+            // records r00 + 4 g .. + 4 out of two aligned 16-byte LDS reads (five dword reads at a stride of 4 dwords were 4-way bank conflicts)
+            const u32x4v va = *(const u32x4v*)(lrec + 4 * g), vb = *(const u32x4v*)(lrec + 4 * g + 4);      // lrec has 8 words of slack
+            const u32 e0 = r00 ? va.y : va.x, e1 = r00 ? va.z : va.y, e2 = r00 ? va.w : va.z, e3 = r00 ? vb.x : va.w, e4 = r00 ? vb.y : vb.x;
+            const u32 W0 = e0 | (e1 << 24), W1 = (e1 >> 8) | (e2 << 16), W2 = (e2 >> 16) | (e3 << 8), W3 = e4;
+            cw[3 * g] = __builtin_amdgcn_alignbyte(W1, W0, ph); cw[3 * g + 1] = __builtin_amdgcn_alignbyte(W2, W1, ph);
+            cw[3 * g + 2] = __builtin_amdgcn_alignbyte(W3, W2, ph);
+        }
+        for (u32 d = 3 * ng + threadIdx.x; d < ndw; d += 256) {     // the last one or two dwords
+            const u32 q = hb + 4 * d;
+            const u32 r = (q * 43691u) >> 17, ph2 = q - 3 * r;      // q / 3 exactly (q < 2^16)
+            const unsigned long long two = (unsigned long long)lrec[r] | ((unsigned long long)lrec[r + 1] << 24);
+            cw[d] = (u32)(two >> (8 * ph2));
+        }
+    } else {
+        for (u32 d = threadIdx.x; d < ndw; d += 256) {
+            const u32 q = hb + 4 * d;                               // first stream byte of this dword
+            cw[d] = lrec[q] | (lrec[q + 1] << 8) | (lrec[q + 2] << 16) | (lrec[q + 3] << 24);
+        }
     }
     const u32 tail0 = hb + 4 * ndw;
     if (threadIdx.x < nbytes - tail0) co[tail0 + threadIdx.x] = stream_byte(tail0 + threadIdx.x);
@@ -471,6 +510,7 @@ int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, in
     PB3D_REQUIRE(ncolors >= 0 && ncolors <= 32, "pb3d_points: at most 32 colours");
     PB3D_REQUIRE(ncolors == 0 || (C == 3 && colors), "pb3d_points: colour selection needs an RGB grid");
     p->A1 = A1; p->A2 = A2;
+    p->packed = (stride == 1 && A0 < (1 << 21) && A1 < (1 << 21) && A2 < (1 << 21) && A2 >= 64 && A0 * A1 * A2 <= 0xffffffffll) ? 1 : 0;
     const i64 L0 = (A0 + stride - 1) / stride;
     p->L1 = (A1 + stride - 1) / stride; p->L2 = (A2 + stride - 1) / stride;
     p->nlat = L0 * p->L1 * p->L2;
