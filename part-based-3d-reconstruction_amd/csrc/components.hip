@@ -32,15 +32,15 @@ __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labe
         const u32 row = (u32)__builtin_amdgcn_readfirstlane((int)rw);
         const u32 a0 = pb3d_div(row, m1), a1 = row - a0 * m1.d;
         const int* lrow = labels + (i64)row * A2;
-        for (int t0 = 0; t0 < nwin; t0 += 4) {
-            int Lq[4];
+        for (int t0 = 0; t0 < nwin; t0 += 16) {
+            int Lq[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                       // four windows' loads in flight before any is used
+            for (int q = 0; q < 16; ++q) {                                      // sixteen windows' loads in flight before any is used
                 const int a2 = 64 * (t0 + q) + lane;
                 Lq[q] = a2 < A2 ? lrow[a2] : 0;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 16; ++q) {
                 const int a2 = 64 * (t0 + q) + lane;
                 const int L = Lq[q];
                 const int before = __shfl_up(L, 1);
