@@ -56,6 +56,7 @@ int pb3d_create(int device, pb3d_ctx** out) {
         ctx->tune_rot8_ty = env_int("PB3D_ROT8_TY");
         const char* names[6] = {"PB3D_TUNE0", "PB3D_TUNE1", "PB3D_TUNE2", "PB3D_TUNE3", "PB3D_TUNE4", "PB3D_TUNE5"};
         for (int i = 0; i < 6; ++i) ctx->tune_misc[i] = env_int(names[i]);
+        ctx->tune_uncap = env_int("PB3D_UNCAP");
     }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);

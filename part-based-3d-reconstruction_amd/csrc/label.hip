@@ -132,24 +132,54 @@ __global__ __launch_bounds__(256) void k_label_to_rgb(const u8* __restrict__ lab
 
 // apply_colored_mask_to_voxel_grid on labels: out[x,y,z] = carved[x,y,z] == 1 ? label_hw[y,x] : 0
 __global__ __launch_bounds__(256) void k_label_apply(const u8* __restrict__ carved, const u8* __restrict__ label_hw, i64 W, i64 H, i64 D,
-                                                     u8* __restrict__ out) {
+                                                     u8* __restrict__ out, i64 v_first = 0) {
     const i64 nvox = W * H * D;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (i64)gridDim.x * blockDim.x) {
+    for (i64 i = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (i64)gridDim.x * blockDim.x) {
         const i64 col = i / D, x = col / H, y = col - x * H;
         out[i] = carved[i] == 1 ? label_hw[y * W + x] : (u8)0;
     }
 }
 
 
+// the same, 16 voxels of the flat stream per thread (fewer than 2^32 voxels, D >= 16, 16-byte aligned output): a group lies in one
+// (x,y) column or straddles two; exact u32 divisions (the per-voxel form spends two 64-bit divisions per BYTE)
+__global__ __launch_bounds__(256) void k_label_apply16(const u8* __restrict__ carved, const u8* __restrict__ label_hw, i64 W, i64 H, i64 ngroups,
+                                                       pb3d_magic mD, pb3d_magic mH, u8* __restrict__ out) {
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
+        const u32 v0 = (u32)(16 * g);
+        const u32 col = pb3d_div(v0, mD), x = pb3d_div(col, mH), y = col - x * mH.d;
+        const u32 bnd = (col + 1) * mD.d - v0;                      // voxels of the group in column `col` (>= 1)
+        const u32 L0 = label_hw[(i64)y * W + x];
+        u32 L1 = L0;
+        if (bnd < 16u) { const u32 x1 = y + 1 < mH.d ? x : x + 1, y1 = y + 1 < mH.d ? y + 1 : 0u; L1 = label_hw[(i64)y1 * W + x1]; }
+        const u32x4 cv = *(const u32x4*)(carved + 16 * g);
+        const u32 cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        u32 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 t = cw[j] ^ 0x01010101u;                                          // a byte equal to 1 becomes 0
+            const u32 z = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;          // bit 7 set <=> the byte is non-zero
+            const u32 e = ((~z & 0x80808080u) >> 7) * 0xffu;                             // 0xff where carved == 1
+            u32 lab = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) lab |= ((u32)(4 * j + b) < bnd ? L0 : L1) << (8 * b);
+            o[j] = e & lab;
+        }
+        u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+        *(u32x4*)(out + 16 * g) = r;
+    }
+}
+
 // part_carve on labels (reference utils/voxel_carving_utils.py:139-160 with the colour grid in label form), per job:
 //   occ[v]  = mask_sub[xy] && label[v] != 0 ; carved = process_voxel_grid(occ, mask_carve, angle) ; keep[v] |= mask_sub[xy] && carved[v]
 //   out[v]  = keep[v] ? label[v] : 0
 // G = 16 voxels per thread when a column is a whole number of 16-byte groups, else 1.
 template <int G>
-__global__ __launch_bounds__(256) void k_label_occ(const u8* __restrict__ label, const u8* __restrict__ mask_sub, u8* __restrict__ occ, i64 nvox, i64 D) {
+__global__ __launch_bounds__(256) void k_label_occ(const u8* __restrict__ label, const u8* __restrict__ mask_sub, u8* __restrict__ occ, i64 nvox, i64 D,
+                                                   pb3d_magic mD, int small) {
     const i64 ngroups = nvox / G;
     for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
-        const bool m = mask_sub[(g * G) / D] != 0;
+        const bool m = mask_sub[small ? (i64)pb3d_div((u32)(g * G), mD) : (g * G) / D] != 0;
         if (G == 16) {
             u32x4 r = (u32x4)(0u);
             if (m) {
@@ -169,10 +199,10 @@ __global__ __launch_bounds__(256) void k_label_occ(const u8* __restrict__ label,
 
 template <int G>
 __global__ __launch_bounds__(256) void k_label_keep_or(const u8* __restrict__ carved, const u8* __restrict__ mask_sub, u8* __restrict__ keep, i64 nvox,
-                                                       i64 D, int first) {
+                                                       i64 D, int first, pb3d_magic mD, int small) {
     const i64 ngroups = nvox / G;
     for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (i64)gridDim.x * blockDim.x) {
-        const bool m = mask_sub[(g * G) / D] != 0;
+        const bool m = mask_sub[small ? (i64)pb3d_div((u32)(g * G), mD) : (g * G) / D] != 0;
         if (G == 16) {
             u32x4 r = (u32x4)(0u);
             if (m) {
@@ -290,8 +320,15 @@ int pb3d_global_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const ui
     PB3D_HIP(hipMemsetAsync(ones, 1, (size_t)nvox, ctx->stream));
     PB3D_TRY(pb3d_transpose_mask_dev(ctx, d_bin_hw, H, W, (u8*)mwh));
     PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
-    hipLaunchKernelGGL(k_label_apply, dim3(pb3d_stream_blocks(ctx, nvox, 256, 16)), dim3(256), 0, ctx->stream, (const u8*)carved, d_label_hw, W, H, D,
-                       d_out);
+    if (nvox < (1ll << 32) && D >= 16 && (((uintptr_t)d_out) & 15u) == 0) {
+        const i64 ngroups = nvox / 16;
+        hipLaunchKernelGGL(k_label_apply16, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 16)), dim3(256), 0, ctx->stream, (const u8*)carved, d_label_hw, W, H,
+                           ngroups, pb3d_make_magic((u32)D), pb3d_make_magic((u32)H), d_out);
+        if (16 * ngroups < nvox)
+            hipLaunchKernelGGL(k_label_apply, dim3(1), dim3(256), 0, ctx->stream, (const u8*)carved, d_label_hw, W, H, D, d_out, 16 * ngroups);
+    } else
+        hipLaunchKernelGGL(k_label_apply, dim3(pb3d_stream_blocks(ctx, nvox, 256, 16)), dim3(256), 0, ctx->stream, (const u8*)carved, d_label_hw, W, H, D,
+                           d_out);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
@@ -313,19 +350,21 @@ int pb3d_part_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_label, int64_t W, 
     const bool wide = D % 16 == 0 && ((((uintptr_t)d_label) | ((uintptr_t)d_out)) & 15u) == 0;
     const unsigned blocks = pb3d_stream_blocks(ctx, wide ? nvox / 16 : nvox, 256, 8);
     bool any = false;
+    const pb3d_magic mDl = pb3d_make_magic((u32)(D > 0 && D < (1ll << 31) ? D : 1));
+    const int smalll = (nvox < (1ll << 32) && D < (1ll << 31)) ? 1 : 0;
     for (int j = 0; j < njobs; ++j) {
         if (job_skip[j]) continue;
         const u8* ms = d_mask_sub + (i64)j * W * H;
         const u8* mc = d_mask_carve + (i64)j * W * H;
         PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));          // tables of the job's first rotation, behind the kernels below
-        if (wide) hipLaunchKernelGGL(k_label_occ<16>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D);
-        else hipLaunchKernelGGL(k_label_occ<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D);
+        if (wide) hipLaunchKernelGGL(k_label_occ<16>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D, mDl, smalll);
+        else hipLaunchKernelGGL(k_label_occ<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D, mDl, smalll);
         PB3D_CHECK_LAUNCH();
         PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
         for (int jn = j + 1; jn < njobs; ++jn)                                  // ... and of the next job's, behind this job's last kernels
             if (!job_skip[jn]) { PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jn])); break; }
-        if (wide) hipLaunchKernelGGL(k_label_keep_or<16>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1);
-        else hipLaunchKernelGGL(k_label_keep_or<1>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1);
+        if (wide) hipLaunchKernelGGL(k_label_keep_or<16>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, mDl, smalll);
+        else hipLaunchKernelGGL(k_label_keep_or<1>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, mDl, smalll);
         PB3D_CHECK_LAUNCH();
         any = true;
     }

@@ -254,7 +254,7 @@ bool f32_path(const ProjParams& P, ProjF32* F) {
     return true;
 }
 inline int vec_ok(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
-inline unsigned f32_blocks(pb3d_ctx* ctx, i64 n) { return pb3d_stream_blocks(ctx, n / 4 + 1, 256, 16); }
+inline unsigned f32_blocks(pb3d_ctx* ctx, i64 n) { return pb3d_stream_blocks(ctx, n / 4 + 1, 256, 0); }      // one workgroup per 1024 points
 
 struct IouParams {
     int ncolors;

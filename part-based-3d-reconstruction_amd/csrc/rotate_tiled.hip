@@ -1040,12 +1040,13 @@ __global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colo
     }
 }
 
+// job_on: bit j = job j takes part (passed by value: a device copy of the flags cost a memcpy and a stream synchronisation per call)
 __global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_sub, const u8* __restrict__ mask_carve,
-                                                    const int* __restrict__ job_on, int nj, i64 npix, u32* __restrict__ A) {
+                                                    u32 job_on, int nj, i64 npix, u32* __restrict__ A) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (i64)gridDim.x * blockDim.x) {
         u32 a = 0;
         for (int j = 0; j < nj; ++j)
-            if (job_on[j] && mask_sub[(i64)j * npix + i] && mask_carve[(i64)j * npix + i]) a |= 1u << j;
+            if (((job_on >> j) & 1u) && mask_sub[(i64)j * npix + i] && mask_carve[(i64)j * npix + i]) a |= 1u << j;
         A[i] = a;
     }
 }
@@ -1219,20 +1220,17 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     u32* bits; int nw;
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-    void *occ = nullptr, *A, *jon;
+    void *occ = nullptr, *A;
 #ifndef PB3D_PART90_RGBSRC
 #define PB3D_PART90_RGBSRC 1
 #endif
     const bool rgbsrc = PB3D_PART90_RGBSRC != 0;
     if (!rgbsrc) PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)(W * H * D), &occ));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)(W * H) * sizeof(u32), &A));
-    PB3D_TRY(pb3d_scratch(ctx, 6, 64 * sizeof(int), &jon));
-    int on[32];
-    for (int j = 0; j < 32; ++j) on[j] = (j < njobs && !job_skip[j]) ? 1 : 0;
-    PB3D_HIP(hipMemcpyAsync(jon, on, sizeof(on), hipMemcpyHostToDevice, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));   // `on` lives on this stack frame
-    hipLaunchKernelGGL(k_job_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, d_mask_carve,
-                       (const int*)jon, njobs, W * H, (u32*)A);
+    u32 on = 0;
+    for (int j = 0; j < 32; ++j) on |= (u32)((j < njobs && !job_skip[j]) ? 1 : 0) << j;
+    hipLaunchKernelGGL(k_job_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, d_mask_carve, on, njobs, W * H,
+                       (u32*)A);
     PB3D_CHECK_LAUNCH();
     if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
     if (rgbsrc && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && H * D < (1ll << 31) && ctx->tune_misc[2] != 2 &&
