@@ -343,9 +343,9 @@ extern "C" int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, in
     hipLaunchKernelGGL(k_ccl_bits, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, ctx->stream, d_grid_rgb, n, ngroups, color24,
                        (unsigned short*)bits);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_init, dim3(pb3d_stream_blocks(ctx, rows, 4, 16)), dim3(256), 0, ctx->stream, (const u32*)bits, nbw, rows, (int)A2, parent);
+    hipLaunchKernelGGL(k_ccl_init, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u32*)bits, nbw, rows, (int)A2, parent);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_merge, dim3(pb3d_stream_blocks(ctx, nwords, 256, 16)), dim3(256), 0, ctx->stream, (const u32*)bits, nwords, mP, m1, (int)A0,
+    hipLaunchKernelGGL(k_ccl_merge, dim3(pb3d_stream_blocks(ctx, nwords, 256, 0)), dim3(256), 0, ctx->stream, (const u32*)bits, nwords, mP, m1, (int)A0,
                        (int)A1, (int)A2, parent);
     PB3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ccl_roots, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, (const u32*)bits, nwords, mP, (int)A2, (const int*)parent,
@@ -356,7 +356,7 @@ extern "C" int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, in
     hipLaunchKernelGGL(k_ccl_number, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, nwords, mP, (int)A2, (const u64*)rootbits,
                        (const u32*)chunk_base, parent);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_finish, dim3(pb3d_stream_blocks(ctx, rows, 4, 16)), dim3(256), 0, ctx->stream, (const u32*)bits, nbw, rows, (int)A2, parent);
+    hipLaunchKernelGGL(k_ccl_finish, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u32*)bits, nbw, rows, (int)A2, parent);
     PB3D_CHECK_LAUNCH();
     i64 nroots = 0;
     PB3D_HIP(hipMemcpyAsync(&nroots, total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
