@@ -3,14 +3,16 @@
 //
 // Round-2 form.  The first version kept a byte mask, a parent array, a root array and the caller's label array (14 B/voxel of state),
 // walked one thread per voxel in every pass and ranked the roots through the float point extractor: 10.9 ms at 1024^3.  Here
-//   * membership is ONE BIT per voxel (k_ccl_bits: the only pass that reads the colour grid, 16 voxels per thread);
+//   * membership is ONE BIT per voxel, formed by the pass that also initialises the forest (k_ccl_init: the only pass that reads the
+//     colour grid -- a wavefront per row, 16 voxels per lane);
 //   * the caller's int32 label array IS the union-find forest: while the forest is being built a member holds ~parent (negative),
 //     a non-member holds 0 -- already its final value -- and a finished voxel holds its label (positive), so the three states never
 //     collide and a walker that meets a positive value has met its answer;
-//   * all passes work in the ROW FRAME: a row (fastest axis, A2 voxels) is cut into 64-bit windows fetched from the flat bit stream
-//     with a funnel shift, so A2 needs no alignment, the neighbours of a window along the two slow axes are the same window one row
-//     / one plane on, and the links are pure bit arithmetic: a link (v, v+s) is made only at the FIRST voxel of every overlap of two
-//     runs, i.e. one union per pair of touching runs instead of one per touching face;
+//   * all passes work in the ROW FRAME: a row (fastest axis, A2 voxels) is ceil(A2 / 64) 64-bit windows of a row-padded bit array
+//     (word row * P + t; the bits past A2 in a row's last word are zero), so A2 needs no alignment, the neighbours of a window along
+//     the two slow axes are the same window one row / one plane on (+P, +A1 * P words), and the links are pure bit arithmetic: a link
+//     (v, v+s) is made only at the FIRST voxel of every overlap of two runs, i.e. one union per pair of touching runs instead of one
+//     per touching face;
 //   * union-find nodes are whole runs (k_ccl_init hands every voxel of a run the run's first voxel as parent, carrying the start
 //     across windows), the smaller index always becomes the root, so root == first voxel in raster order and label == rank of
 //     the root among all roots: a popcount scan over per-window root bit masks (k_ccl_roots / k_ccl_scan / k_ccl_number);
@@ -49,117 +51,103 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     }
 }
 
-// 64 bits of the flat bit stream starting at bit position `pos` (the buffer carries two dwords of zero slack past the last voxel)
-__device__ __forceinline__ u64 window(const u32* __restrict__ bits, u32 pos) {
-    const u32 i = pos >> 5, sh = pos & 31u;
-    const u32 w0 = bits[i], w1 = bits[i + 1], w2 = bits[i + 2];
-    return (u64)__builtin_amdgcn_alignbit(w1, w0, sh) | ((u64)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
-}
 __device__ __forceinline__ u64 low_mask(int nbits) { return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull); }
-// The windows of a row chunk, one per lane, from ONE load per lane: lane l fetches dword l of the stream from the chunk's first bit
-// on, window l is cut out of dwords 2l .. 2l+2 with cross-lane reads (kChunkWin windows need 61 dwords).  The per-window loops of
-// the row kernels then run on registers only -- fetching every window separately made each row a chain of 16 dependent loads.
-constexpr int kChunkWin = 30;
-
-__device__ __forceinline__ u64 chunk_windows(const u32* __restrict__ bits, u32 pos0, int cw, int valid_bits, u32 nbw, int lane) {
-    u32 wi = (pos0 >> 5) + (u32)lane;
-    wi = wi < nbw ? wi : nbw - 1u;
-    const u32 W = bits[wi], sh = pos0 & 31u;
-    const u32 w0 = (u32)__shfl((int)W, 2 * lane), w1 = (u32)__shfl((int)W, 2 * lane + 1), w2 = (u32)__shfl((int)W, 2 * lane + 2);
-    const u64 w = (u64)__builtin_amdgcn_alignbit(w1, w0, sh) | ((u64)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
-    return lane < cw ? w & low_mask(valid_bits - 64 * lane) : 0ull;
-}
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)v, l);
 }
-__device__ __forceinline__ u32 bit_at(const u32* __restrict__ bits, u32 pos) { return (bits[pos >> 5] >> (pos & 31u)) & 1u; }
+typedef u32 u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
 
-// ---- membership bits ------------------------------------------------------------------------------------------------------
-// 16 voxels (48 bytes, three 16-byte loads) per thread -> one u16 of the bit stream; groups past the grid write zeros (the slack)
-__global__ __launch_bounds__(256) void k_ccl_bits(const u8* __restrict__ grid, i64 n, i64 ngroups, u32 color24, unsigned short* __restrict__ bits16) {
-    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;                 // one group per thread: a block is 12 KB of the grid
-    if (g < ngroups) {
-        const i64 v0 = 16 * g;
-        u32 out = 0;
-        if (v0 < n) {
-            u32 w[13];
-            w[12] = 0u;
-            if (v0 + 16 <= n) {
-                const u32x4c* p = (const u32x4c*)(grid + 3 * v0);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { const u32x4c t = p[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    u32 t = 0;
-                    for (int b = 0; b < 4; ++b) { const i64 o = 3 * v0 + 4 * k + b; if (o < 3 * n) t |= (u32)grid[o] << (8 * b); }
-                    w[k] = t;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int j = (3 * i) >> 2, sh = (3 * i) & 3;
-                out |= (u32)((__builtin_amdgcn_alignbyte(w[j + 1], w[j], (u32)sh) & 0x00ffffffu) == color24) << i;
-            }
-            const i64 left = n - v0;
-            if (left < 16) out &= (1u << left) - 1u;
-        }
-        bits16[g] = (unsigned short)out;
-    }
-}
+// ---- membership bits + forest initialisation: one wavefront per row ---------------------------------------------------------
+// A row is taken in chunks of 1024 voxels: lane l reads the 48 bytes of voxels 16 l .. 16 l + 15 of the chunk (16-byte loads at
+// whatever alignment the row has), compares them with the colour, and lanes 0..15 collect the chunk's sixteen 64-bit windows with
+// cross-lane reads (window l = the masks of lanes 4 l .. 4 l + 3).  The windows go to the padded bit array for the later passes and
+// drive the forest initialisation at once: one lane per voxel of window tt -- member: ~(first voxel of the run), non-member: 0; the run
+// start is carried across windows and chunks.
+constexpr int kChunkVox = 1024;
 
-// ---- forest initialisation: one wavefront per row, one lane per voxel of the current 64-voxel window ------------------------
-// member: ~(first voxel of the run) ; non-member: 0.  The run start is carried across the windows of a row.
-__global__ __launch_bounds__(256) void k_ccl_init(const u32* __restrict__ bits, u32 nbw, i64 rows, int A2, int* __restrict__ parent) {
+__global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 rows, int A2, int P, u32 color24, u64* __restrict__ bits,
+                                                  int* __restrict__ parent) {
     const int lane = threadIdx.x & 63;
     const u64 le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-    const int nwin = (A2 + 63) >> 6;
+    const i64 nbytes = 3 * rows * (i64)A2;
     for (i64 rw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); rw < rows; rw += (i64)gridDim.x * 4) {
         const u32 row = (u32)__builtin_amdgcn_readfirstlane((int)rw);
         const u32 base = row * (u32)A2;
         u32 carry_start = 0, prevbit = 0;
-        for (int t0 = 0; t0 < nwin; t0 += kChunkWin) {
-            const int cw = nwin - t0 < kChunkWin ? nwin - t0 : kChunkWin;
-            const u64 wl = chunk_windows(bits, base + 64u * (u32)t0, cw, A2 - 64 * t0, nbw, lane);
+        for (int c0 = 0; c0 < A2; c0 += kChunkVox) {
+            // ---- 16 membership bits of this lane's voxels c0 + 16 lane .. + 15
+            const int v = c0 + 16 * lane;
+            u32 m16 = 0;
+            if (v < A2) {
+                const i64 boff = 3 * ((i64)base + v);
+                u32 w[13];
+                w[12] = 0u;
+                if (boff + 48 <= nbytes) {                               // (past the row's end these are the next row's voxels: masked off below)
+                    const u32x4a1* p = (const u32x4a1*)(grid + boff);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const u32x4a1 t = p[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
+                } else {                                                 // the grid's last 47 bytes: byte by byte
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        u32 t = 0;
+                        for (int b = 0; b < 4; ++b) { const i64 o = boff + 4 * k + b; if (o < nbytes) t |= (u32)grid[o] << (8 * b); }
+                        w[k] = t;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+                    m16 |= (u32)((__builtin_amdgcn_alignbyte(w[j + 1], w[j], (u32)sh) & 0x00ffffffu) == color24) << i;
+                }
+                if (v + 16 > A2) m16 &= (1u << (A2 - v)) - 1u;
+            }
+            // ---- the chunk's windows, one per lane 0..15
+            const u64 wl = (u64)(u32)__shfl((int)m16, 4 * lane) | ((u64)(u32)__shfl((int)m16, 4 * lane + 1) << 16) |
+                           ((u64)(u32)__shfl((int)m16, 4 * lane + 2) << 32) | ((u64)(u32)__shfl((int)m16, 4 * lane + 3) << 48);
+            const int t0 = c0 >> 6;
+            const int cw = (A2 - c0 + 63) >> 6 < 16 ? (A2 - c0 + 63) >> 6 : 16;
+            if (lane < cw) bits[(i64)row * P + t0 + lane] = wl;
+            // ---- forest initialisation, one lane per voxel of window tt
             for (int tt = 0; tt < cw; ++tt) {
                 const int t = t0 + tt;
-                const u64 w = readlane64(wl, tt);
-                const u64 starts = w & ~((w << 1) | (u64)prevbit);
+                const u64 w64 = readlane64(wl, tt);
+                const u64 starts = w64 & ~((w64 << 1) | (u64)prevbit);
                 if (lane < A2 - 64 * t) {
                     int val = 0;
-                    if ((w >> lane) & 1ull) {
+                    if ((w64 >> lane) & 1ull) {
                         const u64 upto = starts & le;
-                        const u32 s = upto ? (u32)(64 * t + 63 - __clzll((long long)upto)) : carry_start;
-                        val = ~(int)(base + s);
+                        const u32 s0 = upto ? (u32)(64 * t + 63 - __clzll((long long)upto)) : carry_start;
+                        val = ~(int)(base + s0);
                     }
                     parent[base + 64u * (u32)t + (u32)lane] = val;
                 }
-                if ((w >> 63) && starts) carry_start = (u32)(64 * t + 63 - __clzll((long long)starts));
-                prevbit = (u32)(w >> 63);
+                if ((w64 >> 63) && starts) carry_start = (u32)(64 * t + 63 - __clzll((long long)starts));
+                prevbit = (u32)(w64 >> 63);
             }
         }
     }
 }
 
 // ---- links along the two slow axes: one lane per 64-voxel window of a row ----------------------------------------------------
-__global__ __launch_bounds__(256) void k_ccl_merge(const u32* __restrict__ bits, i64 nwords, pb3d_magic mP, pb3d_magic m1, int A0, int A1, int A2,
+__global__ __launch_bounds__(256) void k_ccl_merge(const u64* __restrict__ bits, i64 nwords, pb3d_magic mP, pb3d_magic m1, int A0, int A1, int A2,
                                                    int* parent) {
+    const i64 P = mP.d;
     for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < nwords; idx += (i64)gridDim.x * blockDim.x) {
+        const u64 M = bits[idx];
+        if (!M) continue;
         const u32 row = pb3d_div((u32)idx, mP), t = (u32)idx - row * mP.d;
         const u32 a0 = pb3d_div(row, m1), a1 = row - a0 * m1.d;
         const u32 base = row * (u32)A2 + 64u * t;
-        const u64 vm = low_mask(A2 - 64 * (int)t);
-        const u64 M = window(bits, base) & vm;
-        if (!M) continue;
-        const u32 pm = t ? bit_at(bits, base - 1u) : 0u;
+        const u64 pm = t ? bits[idx - 1] >> 63 : 0ull;
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             if (dir == 0 ? a1 + 1 >= (u32)A1 : a0 + 1 >= (u32)A0) continue;
             const u32 s = dir == 0 ? (u32)A2 : (u32)A1 * (u32)A2;
-            const u64 c = M & window(bits, base + s);
+            const i64 nidx = idx + (dir == 0 ? P : (i64)A1 * P);            // the same window one row / one plane on
+            const u64 c = M & bits[nidx];
             if (!c) continue;
-            const u32 pc = (pm && t) ? bit_at(bits, base + s - 1u) : 0u;
-            u64 reps = c & ~((c << 1) | (u64)pc);               // first voxel of every overlap of two runs
+            const u64 pc = (pm && t) ? bits[nidx - 1] >> 63 : 0ull;
+            u64 reps = c & ~((c << 1) | pc);                    // first voxel of every overlap of two runs
             while (reps) {
                 const int i = __ffsll((unsigned long long)reps) - 1;
                 reps &= reps - 1;
@@ -172,17 +160,16 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const u32* __restrict__ bits,
 // ---- roots: run starts that are still their own parent; 1024 windows per block, 4 consecutive windows per thread -------------
 constexpr int kWinPerBlock = 1024;
 
-__device__ __forceinline__ u64 run_starts(const u32* __restrict__ bits, u32 idx, const pb3d_magic mP, int A2, u32* base_out) {
+__device__ __forceinline__ u64 run_starts(const u64* __restrict__ bits, u32 idx, const pb3d_magic mP, int A2, u32* base_out) {
     const u32 row = pb3d_div(idx, mP), t = idx - row * mP.d;
-    const u32 base = row * (u32)A2 + 64u * t;
-    const u64 w = window(bits, base) & low_mask(A2 - 64 * (int)t);
-    *base_out = base;
+    *base_out = row * (u32)A2 + 64u * t;
+    const u64 w = bits[idx];
     if (!w) return 0ull;
-    const u32 pm = t ? bit_at(bits, base - 1u) : 0u;
-    return w & ~((w << 1) | (u64)pm);
+    const u64 pm = t ? bits[idx - 1] >> 63 : 0ull;
+    return w & ~((w << 1) | pm);
 }
 
-__global__ __launch_bounds__(256) void k_ccl_roots(const u32* __restrict__ bits, i64 nwords, pb3d_magic mP, int A2, const int* parent,
+__global__ __launch_bounds__(256) void k_ccl_roots(const u64* __restrict__ bits, i64 nwords, pb3d_magic mP, int A2, const int* parent,
                                                    u64* __restrict__ rootbits, u32* __restrict__ chunk_count) {
     __shared__ u32 wsum[4];
     u32 cnt = 0;
@@ -269,19 +256,20 @@ __global__ __launch_bounds__(256) void k_ccl_number(i64 nwords, pb3d_magic mP, i
 // ---- labels: one wavefront per row; the first lane of every run walks to a finished entry, the run's lanes store its label -----
 // A walker may pass through entries other wavefronts are finishing at the same moment: it then reads either the old ~parent (still a
 // valid path) or the label itself (the answer).
-__global__ __launch_bounds__(256) void k_ccl_finish(const u32* __restrict__ bits, u32 nbw, i64 rows, int A2, int* parent) {
+constexpr int kChunkWin = 32;                                    // windows of a row handled together by the last pass (2048 voxels)
+
+__global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits, i64 rows, int A2, int P, int* parent) {
     __shared__ int table[4][kChunkWin][32];                      // labels of the runs that start in window t, in order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u64 le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-    const int nwin = (A2 + 63) >> 6;
     for (i64 rw = (i64)blockIdx.x * 4 + wv; rw < rows; rw += (i64)gridDim.x * 4) {
         const u32 row = (u32)__builtin_amdgcn_readfirstlane((int)rw);
         const u32 base = row * (u32)A2;
         int carry_label = 0;
         u32 prevbit = 0;
-        for (int t0 = 0; t0 < nwin; t0 += kChunkWin) {
-            const int cw = nwin - t0 < kChunkWin ? nwin - t0 : kChunkWin;
-            const u64 wl = chunk_windows(bits, base + 64u * (u32)t0, cw, A2 - 64 * t0, nbw, lane);
+        for (int t0 = 0; t0 < P; t0 += kChunkWin) {
+            const int cw = P - t0 < kChunkWin ? P - t0 : kChunkWin;
+            const u64 wl = lane < cw ? bits[(i64)row * P + t0 + lane] : 0ull;
             // phase A, one lane per WINDOW: all the walks of the chunk are in flight together
             const u64 before = __shfl_up((unsigned long long)wl, 1);
             const u64 pb = lane == 0 ? (u64)prevbit : before >> 63;
@@ -326,10 +314,9 @@ extern "C" int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, in
     PB3D_REQUIRE(n < (1ll << 31), "pb3d_label_color: grid too large for 32-bit labels");
     PB3D_REQUIRE(d_grid_rgb && d_labels, "pb3d_label_color: null buffer");
     const i64 rows = A0 * A1, P = (A2 + 63) / 64, nwords = rows * P;
-    const i64 ngroups = 4 * (n / 64 + 2);                              // u16 groups: the grid plus >= 64 bits of zero slack, whole u64s
     const i64 nchunks = (nwords + kWinPerBlock - 1) / kWinPerBlock;
     void *bits, *rootbits, *chunks;
-    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)ngroups * 2, &bits));
+    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nwords * 8, &bits));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nwords * 8, &rootbits));
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nchunks * 8 + 16, &chunks));
     u32* chunk_count = (u32*)chunks;
@@ -338,17 +325,14 @@ extern "C" int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, in
     const u32 color24 = (u32)color[0] | ((u32)color[1] << 8) | ((u32)color[2] << 16);
     const pb3d_magic mP = pb3d_make_magic((u32)P), m1 = pb3d_make_magic((u32)A1);
     int* parent = (int*)d_labels;
-    const u32 nbw = (u32)(ngroups / 2);                                // dwords in the bit stream
 
-    hipLaunchKernelGGL(k_ccl_bits, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, ctx->stream, d_grid_rgb, n, ngroups, color24,
-                       (unsigned short*)bits);
+    hipLaunchKernelGGL(k_ccl_init, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24, (u64*)bits,
+                       parent);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_init, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u32*)bits, nbw, rows, (int)A2, parent);
-    PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_merge, dim3(pb3d_stream_blocks(ctx, nwords, 256, 0)), dim3(256), 0, ctx->stream, (const u32*)bits, nwords, mP, m1, (int)A0,
+    hipLaunchKernelGGL(k_ccl_merge, dim3(pb3d_stream_blocks(ctx, nwords, 256, 16)), dim3(256), 0, ctx->stream, (const u64*)bits, nwords, mP, m1, (int)A0,
                        (int)A1, (int)A2, parent);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_roots, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, (const u32*)bits, nwords, mP, (int)A2, (const int*)parent,
+    hipLaunchKernelGGL(k_ccl_roots, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, (const u64*)bits, nwords, mP, (int)A2, (const int*)parent,
                        (u64*)rootbits, chunk_count);
     PB3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ccl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)chunk_count, nchunks, chunk_base, total);
@@ -356,7 +340,7 @@ extern "C" int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, in
     hipLaunchKernelGGL(k_ccl_number, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, nwords, mP, (int)A2, (const u64*)rootbits,
                        (const u32*)chunk_base, parent);
     PB3D_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ccl_finish, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u32*)bits, nbw, rows, (int)A2, parent);
+    hipLaunchKernelGGL(k_ccl_finish, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P, parent);
     PB3D_CHECK_LAUNCH();
     i64 nroots = 0;
     PB3D_HIP(hipMemcpyAsync(&nroots, total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
