@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_color_apply16(const u8* __restrict__ ca
             const i64 bnd = FLAT ? (xy + 1) * D - 16 * g : 16;     // voxels of the group that belong to column xy
             if (!FLAT || bnd >= 16) expand16(keep16, px[0], px[1], px[2], w);
             else {
-                const i64 xy1 = xy + 1, x1 = y + 1 < H ? x : x + 1, y1 = y + 1 < H ? y + 1 : 0;
+                const i64 x1 = y + 1 < H ? x : x + 1, y1 = y + 1 < H ? y + 1 : 0;        // the next column in (x, y) order
                 const u8* qx = rgb_hw3 + (y1 * W + x1) * 3;
                 const u32 lo = (1u << bnd) - 1u;
                 u32 w2[12];
@@ -480,6 +480,72 @@ __global__ __launch_bounds__(256) void k_part_merge16(const u32x4* __restrict__ 
     }
 }
 
+// Jobs with angle steps other than 90, merged in ONE pass: job k of the list left its carved occupancy in carvedN + k * nvox, S[xy]
+// has bit k where mask_sub_k[xy] is set; keep[v] = OR_k (carved_k[v] && S[xy] bit k) -- the per-job keep-OR passes (3 B/voxel each) and
+// the keep volume are gone.  MERGE: out[v] = colored[v] where keep (the overlay of the fused 90-degree jobs stays); else the final
+// out[v] = keep ? colored[v] : 0.
+struct JobList { int j[8]; int n; };
+
+__global__ __launch_bounds__(256) void k_sub_bitset(const u8* __restrict__ mask_sub, JobList jl, i64 npix, u32* __restrict__ S) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (i64)gridDim.x * blockDim.x) {
+        u32 a = 0;
+        for (int k = 0; k < jl.n; ++k)
+            if (mask_sub[(i64)jl.j[k] * npix + i]) a |= 1u << k;
+        S[i] = a;
+    }
+}
+
+// 16 keep bits of group g (the volume as a flat stream of 16-voxel groups; a group lies in one (x,y) column or straddles two)
+__device__ __forceinline__ u32 multi_keep16(const u32x4* __restrict__ carvedN, i64 ngroups_stride, int nk, const u32* __restrict__ S, i64 g,
+                                            const pb3d_magic mD) {
+    const u32 v0 = (u32)(16 * g);
+    const u32 col0 = pb3d_div(v0, mD), nfirst = mD.d - (v0 - col0 * mD.d);
+    const u32 s0 = S[col0], s1 = nfirst < 16u ? S[col0 + 1] : 0u;
+    const u32 lowm = nfirst < 16u ? (1u << nfirst) - 1u : 0xffffu;
+    u32 keep16 = 0;
+    for (int k = 0; k < nk; ++k) {
+        const u32 sel = (((s0 >> k) & 1u) ? lowm : 0u) | (((s1 >> k) & 1u) ? (0xffffu & ~lowm) : 0u);
+        if (!sel) continue;
+        const u32x4 c = ld_nt(carvedN + (i64)k * ngroups_stride + g);
+        const u32 cw[4] = {c.x, c.y, c.z, c.w};
+        u32 c16 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c16 |= (byte_of(cw, i) ? 1u : 0u) << i;
+        keep16 |= c16 & sel;
+    }
+    return keep16;
+}
+
+template <bool MERGE>
+__global__ __launch_bounds__(256) void k_part_multi16(const u32x4* __restrict__ colored, const u32x4* __restrict__ carvedN, i64 ngroups_stride, int nk,
+                                                      const u32* __restrict__ S, pb3d_magic mD, u32x4* __restrict__ out, i64 ngroups) {
+    __shared__ u32x4 stage[4][192];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (i64 gw0 = (i64)blockIdx.x * blockDim.x + 64 * wv; gw0 < ngroups; gw0 += (i64)gridDim.x * blockDim.x) {   // wave-uniform
+        const i64 g = gw0 + lane;
+        u32x4 r[3] = {(u32x4)(0u), (u32x4)(0u), (u32x4)(0u)};
+        u32 keep16 = 0;
+        if (g < ngroups) keep16 = multi_keep16(carvedN, ngroups_stride, nk, S, g, mD);
+        if (keep16) {
+            u32 m[12];
+            expand16(keep16, 0xffu, 0xffu, 0xffu, m);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const u32x4 c = ld_s(colored + 3 * g + k);
+                if (MERGE) {
+                    const u32x4 o = ld_s(out + 3 * g + k);
+                    r[k].x = (c.x & m[4 * k]) | (o.x & ~m[4 * k]); r[k].y = (c.y & m[4 * k + 1]) | (o.y & ~m[4 * k + 1]);
+                    r[k].z = (c.z & m[4 * k + 2]) | (o.z & ~m[4 * k + 2]); r[k].w = (c.w & m[4 * k + 3]) | (o.w & ~m[4 * k + 3]);
+                    st_s(out + 3 * g + k, r[k]);
+                } else {
+                    r[k].x = c.x & m[4 * k]; r[k].y = c.y & m[4 * k + 1]; r[k].z = c.z & m[4 * k + 2]; r[k].w = c.w & m[4 * k + 3];
+                }
+            }
+        }
+        if (!MERGE) store48_wave(out, gw0, ngroups, r, stage[wv]);
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
@@ -604,6 +670,37 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
     const i64 ngroups = nvox / 16, vtail = 16 * ngroups;                    // the last nvox % 16 voxels: scalar kernels from vtail on
     const pb3d_magic mD = pb3d_make_magic((u32)(D > 0 ? D : 1));
     const unsigned gblocks = pb3d_stream_blocks(ctx, ngroups > 0 ? ngroups : 1, 256, 8);
+    // up to eight such jobs: each leaves its carved occupancy in its own volume and ONE pass merges them (k_part_multi16); tune misc3 = 2
+    // keeps the job-by-job keep-OR passes
+    JobList jl; jl.n = 0;
+    int nrest = 0;
+    for (int j = 0; j < njobs; ++j)
+        if (!job_skip[j]) { if (jl.n < 8) jl.j[jl.n++] = j; ++nrest; }
+    if (wide && nrest >= 1 && nrest <= 8 && nvox % 16 == 0 && ctx->tune_misc[3] != 2) {
+        void *carvedN, *S;
+        PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox * (size_t)nrest, &carvedN));
+        PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H) * sizeof(u32), &S));
+        for (int k = 0; k < jl.n; ++k) {
+            const int j = jl.j[k];
+            const u8* ms = d_mask_sub + (i64)j * W * H;
+            const u8* mc = d_mask_carve + (i64)j * W * H;
+            PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));      // tables of the job's first rotation, behind the kernels below
+            hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, mD);
+            PB3D_CHECK_LAUNCH();
+            PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carvedN + (i64)k * nvox, (u8*)tmp));
+            if (k + 1 < jl.n) PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jl.j[k + 1]]));
+        }
+        hipLaunchKernelGGL(k_sub_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, jl, W * H, (u32*)S);
+        PB3D_CHECK_LAUNCH();
+        if (base90)
+            hipLaunchKernelGGL(k_part_multi16<true>, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, (const u32x4*)carvedN, ngroups, jl.n,
+                               (const u32*)S, mD, (u32x4*)d_out, ngroups);
+        else
+            hipLaunchKernelGGL(k_part_multi16<false>, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, (const u32x4*)carvedN, ngroups, jl.n,
+                               (const u32*)S, mD, (u32x4*)d_out, ngroups);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
     bool any = false;
     for (int j = 0; j < njobs; ++j) {
         if (job_skip[j]) continue;

@@ -714,6 +714,13 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
                 finally:
                     pb3d_gpu._lib.set_tuning("misc2", 0)
                 assert np.array_equal(got, want), (W, H, D, len(jobs), misc2, int((got != want).sum()))
+            if jobs is JOBS_MIXED:       # the jobs with other angles merged in one pass (default where the volume is whole 16-voxel groups) / job by job
+                pb3d_gpu._lib.set_tuning("misc3", 2)
+                try:
+                    got = pb3d_gpu.part_carve(colored, sem, jobs)
+                finally:
+                    pb3d_gpu._lib.set_tuning("misc3", 0)
+                assert np.array_equal(got, want), (W, H, D, "job by job", int((got != want).sum()))
 
 
 @pytest.mark.gpu
