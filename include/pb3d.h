@@ -249,6 +249,9 @@ int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
                             const int64_t hi[3], uint8_t* d_occ);
 int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
                              int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved);
+/* *d_count (a device int64 the caller has zeroed) += number of non-zero bytes of d_bytes[0..n): the "carved voxels" figure of
+ * left_right_guided_carve's log (reference utils/voxel_carving_utils.py:197), without a host round trip per component. */
+int pb3d_count_nonzero_dev(pb3d_ctx* ctx, const uint8_t* d_bytes, int64_t n, int64_t* d_count);
 int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
                                 const uint8_t new_color[3], uint8_t* d_grid_rgb);
 int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,

@@ -227,9 +227,26 @@ __global__ __launch_bounds__(256) void k_orient4(const u8* __restrict__ grid, u8
     }
 }
 
+// *count += non-zero bytes of b[0..n)
+__global__ __launch_bounds__(256) void k_count_nonzero(const u8* __restrict__ b, i64 n, unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) c += b[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
 }  // namespace
 
 extern "C" {
+
+int pb3d_count_nonzero_dev(pb3d_ctx* ctx, const uint8_t* d_bytes, int64_t n, int64_t* d_count) {
+    PB3D_REQUIRE(ctx != nullptr && n >= 0 && d_count != nullptr, "pb3d_count_nonzero: bad argument");
+    if (n == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_bytes != nullptr, "pb3d_count_nonzero: null buffer");
+    hipLaunchKernelGGL(k_count_nonzero, dim3(pb3d_stream_blocks(ctx, n, 256 * 16, 8)), dim3(256), 0, ctx->stream, d_bytes, n, (unsigned long long*)d_count);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
 
 int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0, int64_t A1, int64_t A2, int64_t ncomp,
                              int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum) {

@@ -285,30 +285,46 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle):
         num = _label(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else 0
         print(f"[{target_color}] 3D components: {num}")
         bbox, _, _ = _component_stats(d_lab, (W, H, D), num)
+        lines = []
         if num:
             _check_angle_step(angle)
             vmax = int(max((b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]) for b in bbox))
-            pmax = int(max((b[3] - b[0]) * (b[4] - b[1]) for b in bbox))
-            d_occ = dev.DeviceBuffer(vmax); d_out = dev.DeviceBuffer(vmax); d_tmp = dev.DeviceBuffer(vmax); d_m = dev.DeviceBuffer(pmax)
-            tmp = [d_occ, d_out, d_tmp, d_m]
+            # every component's 2-D crop mask goes up in ONE transfer and the "carved voxels" counts come back in one: the component
+            # loop then queues kernels only (upstream prints between the steps; the text is the same, it is emitted after the loop)
+            masks, offs, o = [], [], 0
+            for i in range(1, num + 1):
+                x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
+                m = _lib.truth_u8(_mask_to_wh(mask2d[y0:y1, x0:x1], x1 - x0, y1 - y0))
+                masks.append(np.ascontiguousarray(m).reshape(-1)); offs.append(o); o += (m.size + 15) & ~15
+            packed = np.zeros(max(o, 16), np.uint8)
+            for m, off in zip(masks, offs):
+                packed[off:off + m.size] = m
+            d_m = dev.from_numpy(packed)
+            d_occ = dev.DeviceBuffer(vmax); d_out = dev.DeviceBuffer(vmax); d_tmp = dev.DeviceBuffer(vmax)
+            d_cnt = dev.DeviceBuffer(8 * num); d_cnt.zero()
+            tmp = [d_occ, d_out, d_tmp, d_m, d_cnt]
         for i in range(1, num + 1):
             x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
-            print(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
+            lines.append(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
             Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
-            m = _lib.truth_u8(_mask_to_wh(mask2d[y0:y1, x0:x1], Wc, Hc))
-            d_m.upload(m)
             lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
             _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
             if angle < 0:
                 src = d_occ     # empty angle loop: the crop's occupancy is returned as is
             else:
-                dev.process_grid(d_occ, Wc, Hc, Dc, d_m, int(min(angle, 91)), d_out, d_tmp)
+                dev.process_grid(d_occ, Wc, Hc, Dc, d_m.at(offs[i - 1]), int(min(angle, 91)), d_out, d_tmp)
                 src = d_out
-            cnt = C.c_int64(0)
-            _lib.check(lib.pb3d_points_count_dev(ctx, C.c_void_p(src.ptr), Wc, Hc, Dc, 1, None, 0, 1, C.byref(cnt)))
-            print(f"    carved voxels: {cnt.value}")
+            _lib.check(lib.pb3d_count_nonzero_dev(ctx, C.c_void_p(src.ptr), Wc * Hc * Dc, d_cnt.at(8 * (i - 1))))
+            lines.append(None)          # the count of component i, filled in below
             _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
                                                     lo, hi, C.c_void_p(d_carved.ptr)))
+        if num:
+            counts = d_cnt.download((num,), np.int64)
+            k = 0
+            for n_, ln in enumerate(lines):
+                if ln is None:
+                    lines[n_] = f"    carved voxels: {int(counts[k])}"; k += 1
+            print("\n".join(lines))
         dev.sync()
         return d_carved
     except BaseException:
