@@ -254,6 +254,7 @@ int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int3
 int pb3d_count_nonzero_dev(pb3d_ctx* ctx, const uint8_t* d_bytes, int64_t n, int64_t* d_count);
 int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
                                 const uint8_t new_color[3], uint8_t* d_grid_rgb);
+/* d_out may be d_grid_rgb itself (in place: nothing but the painted cells is written). */
 int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
                      int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out);
 /* notebook-1 output orientation, reference utils/voxel_carving_utils.py:384-385:

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void k_recolor_flagged(const int* __restrict__
 // extrude_from_surface, axis 2 (reference :218-228): one wavefront per (x,y) column.  start = index of the
 // first occupied voxel from the chosen side (0 / D-1 for an empty column, like np.argmax), then `depth`
 // cells from there, inside the grid, are painted where valid[x,y].
-__global__ __launch_bounds__(256) void k_extrude_z(const u8* __restrict__ src, u8* __restrict__ dst, const u8* __restrict__ valid_wh,
+// (src and dst may be the same volume: a column is scanned and painted by one wavefront / one thread)
+__global__ __launch_bounds__(256) void k_extrude_z(const u8* src, u8* dst, const u8* __restrict__ valid_wh,
                                                    i64 W, i64 H, i64 D, int plus, int depth, int has_color, u8 cr, u8 cg, u8 cb) {
     const int lane = threadIdx.x & 63;
     const i64 col = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_extrude_z(const u8* __restrict__ src, u
 
 // extrude_from_surface, axis 0 (reference :230-240): columns run along x for every (y,z); valid is indexed
 // [y, z] exactly as upstream indexes its (H,W) mask with the z coordinate (which needs D == W).
-__global__ __launch_bounds__(256) void k_extrude_x(const u8* __restrict__ src, u8* __restrict__ dst, const u8* __restrict__ valid_hw,
+__global__ __launch_bounds__(256) void k_extrude_x(const u8* src, u8* dst, const u8* __restrict__ valid_hw,
                                                    i64 W, i64 H, i64 D, i64 Wmask, int plus, int depth, int has_color, u8 cr, u8 cg,
                                                    u8 cb) {
     const i64 n = H * D;
@@ -350,8 +351,9 @@ int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_
     PB3D_REQUIRE(axis == 0 || axis == 2, "pb3d_extrude: axis must be 0 or 2");
     const i64 n = W * H * D;
     if (n == 0) return PB3D_OK;
-    PB3D_REQUIRE(d_grid_rgb && d_valid && d_out && d_grid_rgb != d_out, "pb3d_extrude: null or aliased buffer");
-    PB3D_HIP(hipMemcpyAsync(d_out, d_grid_rgb, (size_t)n * 3, hipMemcpyDeviceToDevice, ctx->stream));
+    PB3D_REQUIRE(d_grid_rgb && d_valid && d_out, "pb3d_extrude: null buffer");
+    // d_out == d_grid_rgb: in place (a chain of extrusions on a resident grid then moves no volume at all)
+    if (d_out != d_grid_rgb) PB3D_HIP(hipMemcpyAsync(d_out, d_grid_rgb, (size_t)n * 3, hipMemcpyDeviceToDevice, ctx->stream));
     if (depth <= 0) return PB3D_OK;
     const u8 cr = fill_color ? fill_color[0] : 0, cg = fill_color ? fill_color[1] : 0, cb = fill_color ? fill_color[2] : 0;
     if (axis == 2) {

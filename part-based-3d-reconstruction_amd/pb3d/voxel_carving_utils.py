@@ -377,18 +377,20 @@ def _extrude_args(shape3, mask_2d, axis, direction):
     return _lib.truth_u8(valid), vw
 
 
-def _extrude_dev(d_in, d_out, shape3, valid_u8, vw, axis, direction, depth, fill_color):
+def _extrude_dev(d_in, d_out, shape3, valid_u8, vw, axis, direction, depth, fill_color, d_valid=None):
+    """one extrusion on device buffers; d_out may be d_in (in place).  d_valid: the mask already on the device (a chain of calls
+    with one mask uploads it once); the call only queues work."""
     from . import device as dev
     W, H, D = shape3
     fc = None if fill_color is None else np.ascontiguousarray(np.asarray(fill_color).astype(np.uint8).reshape(3))
-    d_v = dev.from_numpy(valid_u8)
+    d_v = d_valid if d_valid is not None else dev.from_numpy(valid_u8)
     try:
         _lib.check(_lib.load().pb3d_extrude_dev(_lib.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_v.ptr), vw, int(axis),
                                                 1 if direction == "+" else 0, int(depth), None if fc is None else _lib.p_u8(fc),
                                                 C.c_void_p(d_out.ptr)))
-        dev.sync()
     finally:
-        d_v.free()
+        if d_valid is None:
+            d_v.free()      # (the block goes back to the context's pool; the stream is in order)
 
 
 def extrude_from_surface(grid, mask_2d, axis, direction="+", depth=5, fill_color=None):
@@ -503,18 +505,23 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
             d_a.free(); live.remove(d_a)
             d_a = d_b
         show(d_a, g.shape, "After part-wise symmetric carving (local symmetry on each part)")
-        # 3. interior extrusion: four directions per part, ping-pong between two buffers
-        d_b = d_in          # the input copy is no longer needed
+        # 3. interior extrusion: four directions per part, IN PLACE (a column is scanned and painted by one wavefront / thread), the
+        #    part's mask uploaded once per axis orientation
+        d_b = d_in          # the input copy is no longer needed (the orientation stage below writes into it)
         sm_full = np.asarray(semantic_mask_full)
         key_full = _color_key(sm_full)
         for part, depth in extrusion_depths.items():
+            if int(depth) <= 0:
+                continue
             mask = _is_color(sm_full, key_full, part_colors_np[part])
-            for axis, direction in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
-                if int(depth) <= 0:
-                    continue
-                vt, vw = _extrude_args((W, H, D), mask, axis, direction)
-                _extrude_dev(d_a, d_b, (W, H, D), vt, vw, axis, direction, depth, part_colors_np[part])
-                d_a, d_b = d_b, d_a
+            for axis in (2, 0):
+                vt, vw = _extrude_args((W, H, D), mask, axis, "+")
+                d_v = dev.from_numpy(vt)
+                try:
+                    for direction in ("+", "-"):
+                        _extrude_dev(d_a, d_a, (W, H, D), vt, vw, axis, direction, depth, part_colors_np[part], d_valid=d_v)
+                finally:
+                    d_v.free()
         show(d_a, g.shape, "After interior extrusion")
         # 4. orientation + back-minaret recolouring
         if recolor_back_minarets:
