@@ -228,6 +228,13 @@ __global__ __launch_bounds__(256) void k_orient4(const u8* __restrict__ grid, u8
     }
 }
 
+__global__ __launch_bounds__(256) void k_stats_init(i64 ncomp, int* __restrict__ bbox, unsigned long long* __restrict__ cnt_sum) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < ncomp; k += (i64)gridDim.x * blockDim.x) {
+        for (int a = 0; a < 3; ++a) { bbox[6 * k + a] = 0x7fffffff; bbox[6 * k + 3 + a] = -1; }
+        for (int a = 0; a < 4; ++a) cnt_sum[4 * k + a] = 0ull;
+    }
+}
+
 // *count += non-zero bytes of b[0..n)
 __global__ __launch_bounds__(256) void k_count_nonzero(const u8* __restrict__ b, i64 n, unsigned long long* __restrict__ count) {
     unsigned long long c = 0;
@@ -259,22 +266,16 @@ int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0,
     void *bb, *cs;
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)ncomp * 6 * sizeof(int), &bb));
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)ncomp * 4 * sizeof(unsigned long long), &cs));
-    // lo = +inf, hi = -1
-    int* hb = (int*)malloc((size_t)ncomp * 6 * sizeof(int));
-    PB3D_REQUIRE(hb != nullptr, "pb3d_component_stats: out of host memory");
-    for (i64 k = 0; k < ncomp; ++k) { for (int a = 0; a < 3; ++a) { hb[6 * k + a] = 0x7fffffff; hb[6 * k + 3 + a] = -1; } }
-    hipError_t e = hipMemcpyAsync(bb, hb, (size_t)ncomp * 6 * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    free(hb);
-    PB3D_HIP(e);
-    PB3D_HIP(hipMemsetAsync(cs, 0, (size_t)ncomp * 4 * sizeof(unsigned long long), ctx->stream));
+    // lo = +inf, hi = -1, sums = 0 (set on the device: an upload of the initial boxes cost a transfer and a synchronisation per call)
+    hipLaunchKernelGGL(k_stats_init, dim3(pb3d_stream_blocks(ctx, ncomp, 256, 8)), dim3(256), 0, ctx->stream, ncomp, (int*)bb, (unsigned long long*)cs);
+    PB3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_comp_stats, dim3(pb3d_stream_blocks(ctx, A0 * A1, 4, 8)), dim3(256), 0, ctx->stream, d_labels, A0 * A1, pb3d_make_magic((u32)A1),
                        (int)A2, (int*)bb, (unsigned long long*)cs);
     PB3D_CHECK_LAUNCH();
     int* hbb = (int*)malloc((size_t)ncomp * 6 * sizeof(int));
     unsigned long long* hcs = (unsigned long long*)malloc((size_t)ncomp * 4 * sizeof(unsigned long long));
     if (!hbb || !hcs) { free(hbb); free(hcs); pb3d_set_error("pb3d_component_stats: out of host memory"); return PB3D_ENOMEM; }
-    e = hipMemcpyAsync(hbb, bb, (size_t)ncomp * 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(hbb, bb, (size_t)ncomp * 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hcs, cs, (size_t)ncomp * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess)
