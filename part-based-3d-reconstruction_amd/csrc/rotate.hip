@@ -1223,6 +1223,17 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
         dict[tid] = (tid == 15 || raw == 0xffffffffu) ? 0u : ((t14 & 0x7fu) | ((t14 >> 7) << 8) | (1u << 16));
     }
     const u32 voff_safe = nunits > 0 ? ti->voff[0] : 0u;          // what lanes without a unit load (and throw away)
+    // ODD: the unit that holds the volume's very last voxels runs into the allocation's slack at plane H - 1; whatever lies there must
+    // not trip the "value > 1" check (no tap addresses those columns).  Only workgroups of the last plane chunk whose footprint
+    // reaches the last source row can hold that unit (risky, uniform); jr = which of this thread's units it is, keep = its bytes inside.
+    const bool risky = ODD && y_end == H && bx0 + ti->nrows >= W;
+    int jr = -1, keep_bytes = 16;
+    if (risky) {
+        const i64 total = W * H * D;
+#pragma unroll
+        for (int j = 0; j < PUPT; ++j)
+            if (uvoff[j] != 0xffffffffu && (H - 1) * D + (i64)uvoff[j] + 16 > total) { jr = j; keep_bytes = (int)(total - (H - 1) * D - (i64)uvoff[j]); }
+    }
     __syncthreads();
     u32 hib = 0;
     // The kernel is bound by VALU issue, not by HBM or LDS (SQ counters: 10 k vector instructions per wave and pass at one per four
@@ -1257,6 +1268,13 @@ __global__ __launch_bounds__(PTHREADS, 4) void k_rotate_bits8p(const u8* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u32x4 dd = d[hh & 1][q];
+                if (ODD && risky && j == jr && yg + q0 + q >= H - 1) {             // plane H - 1 (and its re-reads past the chunk's end): the bytes past the volume are zero
+                    const int kb = keep_bytes;
+                    dd.x &= kb >= 4 ? ~0u : ((1u << (8 * (kb > 0 ? kb : 0))) - 1u);
+                    dd.y &= kb >= 8 ? ~0u : (kb > 4 ? (1u << (8 * (kb - 4))) - 1u : 0u);
+                    dd.z &= kb >= 12 ? ~0u : (kb > 8 ? (1u << (8 * (kb - 8))) - 1u : 0u);
+                    dd.w &= kb >= 16 ? ~0u : (kb > 12 ? (1u << (8 * (kb - 12))) - 1u : 0u);
+                }
                 if (SRCMASK && !((msrc >> (q0 + q)) & 1u)) dd = (u32x4)(0u);      // the folded 0-degree carve: this source row / plane is dropped
                 wv.x |= dd.x << (q0 + q); wv.y |= dd.y << (q0 + q); wv.z |= dd.z << (q0 + q); wv.w |= dd.w << (q0 + q);
                 hib |= (dd.x | dd.y) | (dd.z | dd.w);

@@ -595,6 +595,32 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
                     assert np.array_equal(got, want), (W, H, D, ai, tile, int((got != want).sum()))
 
 
+def test_packed_kernel_odd_rows_with_dirty_slack(pb3d_gpu, oracle):
+    """rows that are not multiples of 16 bytes: the packed generic-angle kernel reads whole 16-byte units, the last one of the volume up
+    to 15 bytes into the allocation's slack.  Whatever lies there (here: 0xff) must neither change a voxel nor send the step to the
+    arithmetic fallback by tripping the 'value > 1' check; same for a volume that ends exactly where its allocation does."""
+    from pb3d import device as dev
+    rng = np.random.default_rng(8)
+    for (W, H, D) in [(300, 16, 357), (355, 9, 355), (271, 40, 333)]:
+        g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
+        m = rng.random((H, W)) < 0.9
+        want = oracle.process_voxel_grid(g, m, 45)
+        n = g.size
+        dirty = np.full(n + 64, 0xff, np.uint8); dirty[:n] = g.ravel()
+        d_in = dev.from_numpy(dirty); d_m = dev.from_numpy(np.ascontiguousarray(m.T).astype(np.uint8))
+        d_o = dev.DeviceBuffer(n); d_t = dev.DeviceBuffer(n)
+        for tile in (0, 256):
+            pb3d_gpu._lib.set_tuning("rotate_tile", tile)
+            try:
+                dev.process_grid(d_in, W, H, D, d_m, 45, d_o, d_t)
+                got = d_o.download((W, H, D))
+            finally:
+                pb3d_gpu._lib.set_tuning("rotate_tile", 0)
+            assert np.array_equal(got, want), (W, H, D, tile, int((got != want).sum()))
+        for b in (d_in, d_m, d_o, d_t):
+            b.free()
+
+
 def test_random_shapes_property(pb3d_gpu, oracle):
     """seeded random sweep over shapes / angle steps / mask densities / value ranges: HIP == oracle, byte for byte."""
     rng = np.random.default_rng(20261004)
