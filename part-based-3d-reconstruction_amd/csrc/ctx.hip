@@ -57,6 +57,8 @@ int pb3d_create(int device, pb3d_ctx** out) {
         const char* names[6] = {"PB3D_TUNE0", "PB3D_TUNE1", "PB3D_TUNE2", "PB3D_TUNE3", "PB3D_TUNE4", "PB3D_TUNE5"};
         for (int i = 0; i < 6; ++i) ctx->tune_misc[i] = env_int(names[i]);
         ctx->tune_uncap = env_int("PB3D_UNCAP");
+        ctx->tune_sliced = env_int("PB3D_SLICED");
+        ctx->tune_s32_gpw = env_int("PB3D_S32_GPW");
     }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
@@ -77,6 +79,7 @@ int pb3d_create(int device, pb3d_ctx** out) {
         e = hipEventCreateWithFlags(&ctx->rot_cache[k].ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->rot_cache[k].used, hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->s32_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         free(ctx);
@@ -107,6 +110,12 @@ int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "rot8_ty")) {
         PB3D_REQUIRE(value >= 0 && value % 8 == 0, "pb3d_set_tuning: rot8_ty is a multiple of 8");
         ctx->tune_rot8_ty = value;
+    } else if (!strcmp(name, "sliced")) {
+        PB3D_REQUIRE(value >= 0 && value <= 2, "pb3d_set_tuning: sliced is 0 (chains), 1 (never) or 2 (single steps too)");
+        ctx->tune_sliced = value;
+    } else if (!strcmp(name, "s32_gpw")) {
+        PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: s32_gpw is a count of plane groups");
+        ctx->tune_s32_gpw = value;
     } else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '5' && !name[5]) {
         ctx->tune_misc[name[4] - '0'] = value;
     } else {
@@ -127,6 +136,7 @@ void pb3d_destroy(pb3d_ctx* ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(ctx->rot_cache[k].ready); (void)hipEventDestroy(ctx->rot_cache[k].used); }
+    (void)hipEventDestroy(ctx->s32_ev);
     (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);

@@ -93,7 +93,7 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
     PB3D_HIP(hipMemsetAsync(ones, 1, (size_t)nvox, ctx->stream));
-    PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
+    PB3D_TRY(pb3d_process_grid_binary_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
     return pb3d_color_apply_dev(ctx, (const u8*)carved, W, H, D, d_rgb_hw3, d_out_slab);
 }
 

@@ -319,7 +319,7 @@ int pb3d_global_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const ui
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));
     PB3D_HIP(hipMemsetAsync(ones, 1, (size_t)nvox, ctx->stream));
     PB3D_TRY(pb3d_transpose_mask_dev(ctx, d_bin_hw, H, W, (u8*)mwh));
-    PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
+    PB3D_TRY(pb3d_process_grid_binary_dev(ctx, (const u8*)ones, W, H, D, (const u8*)mwh, angle_interval, (u8*)carved, (u8*)tmp));
     if (nvox < (1ll << 32) && D >= 16 && (((uintptr_t)d_out) & 15u) == 0) {
         const i64 ngroups = nvox / 16;
         hipLaunchKernelGGL(k_label_apply16, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 16)), dim3(256), 0, ctx->stream, (const u8*)carved, d_label_hw, W, H,
@@ -360,7 +360,7 @@ int pb3d_part_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_label, int64_t W, 
         if (wide) hipLaunchKernelGGL(k_label_occ<16>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D, mDl, smalll);
         else hipLaunchKernelGGL(k_label_occ<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D, mDl, smalll);
         PB3D_CHECK_LAUNCH();
-        PB3D_TRY(pb3d_process_grid_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
+        PB3D_TRY(pb3d_process_grid_binary_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
         for (int jn = j + 1; jn < njobs; ++jn)                                  // ... and of the next job's, behind this job's last kernels
             if (!job_skip[jn]) { PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jn])); break; }
         if (wide) hipLaunchKernelGGL(k_label_keep_or<16>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, mDl, smalll);

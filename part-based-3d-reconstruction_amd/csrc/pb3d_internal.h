@@ -14,7 +14,7 @@ typedef int64_t i64;
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-#define PB3D_NSCRATCH 32
+#define PB3D_NSCRATCH 48
 #define PB3D_POOL_SLOTS 64
 #define PB3D_POOL_LIVE 4096
 
@@ -33,6 +33,8 @@ struct pb3d_ctx {
     int tune_rot8_ty;           // PB3D_ROT8_TY: planes per workgroup of the packed kernel (0 = default)
     int tune_misc[6];           // PB3D_TUNE0..5: experiment switches of kernels under development
     int tune_uncap;             // PB3D_UNCAP=1: every grid-stride kernel gets one workgroup per tile (A/B of the persistent grids)
+    int tune_sliced;            // PB3D_SLICED: 0 = chains of >= 2 rotation steps run bit-sliced (csrc/sliced.hip), 1 = never, 2 = also single steps
+    int tune_s32_gpw;           // PB3D_S32_GPW: plane groups per workgroup of the sliced step kernel (0 = choose)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).
     void* scratch[PB3D_NSCRATCH];
@@ -71,6 +73,9 @@ struct pb3d_ctx {
     } rot_cache[2];
     u64 rot_stamp;
     struct ValidCache { void* buf; u64 gen; i64 W, D; double p[8]; } valid_cache;   // validity bit table of the last 90-degree step (scratch slot 10)
+    // Tile programs of the bit-sliced chain (csrc/sliced.hip, scratch slot 32): valid for these steps on this (W, D)
+    struct S32Cache { bool valid; u64 gen; i64 W, D; int ns; double p[32 * 8]; } s32_cache;
+    hipEvent_t s32_ev;          // recorded behind the slice kernel's "not 0/1" flag copy
     void* flag_ring;            // the ring of "value > 1 seen" flag words of the generic-angle steps (scratch slot 15) and its position
     u64 flag_gen;
     hipStream_t aux_stream;     // table builds that overlap the main stream's kernels
@@ -154,6 +159,12 @@ __device__ __forceinline__ u32 pb3d_div(u32 n, const pb3d_magic g) {
 }
 
 // ---- kernels' host launchers used across translation units ---------------------------------
+// process_voxel_grid through the bit-sliced chain (csrc/sliced.hip); *took = 0: not applicable, nothing written
+int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
+                             int known_binary, int* took);
+// pb3d_process_grid_dev for callers whose grid is 0/1 by construction (occupancy of a colour grid, all-ones): no host wait
+int pb3d_process_grid_binary_dev(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
+                                 u8* d_tmp);
 // queue the table build of a LATER generic-angle step on the auxiliary stream (no-op when the step has no tables or they exist)
 int pb3d_prefetch_rotation(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3]);
 // ... of the first rotation of process_voxel_grid(., ., angle_interval)

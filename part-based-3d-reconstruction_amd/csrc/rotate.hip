@@ -12,44 +12,9 @@
 // All doubles are evaluated with __dmul_rn/__dadd_rn so that no contraction can occur; the file is
 // also compiled with -ffp-contract=off.  The coordinates depend on (x,z) only, so a thread computes
 // them once and re-uses them for every Y-plane of its chunk (the FP64 work is amortised over y).
-#include "pb3d_internal.h"
+#include "rot_common.h"
 
 namespace {
-
-struct RotParams {
-    double m00, m01, m02, off0;
-    double m20, m21, m22, off2;
-};
-
-struct Cell {
-    double wx0, wx1, wz0, wz1;
-    int s0, s2;  // floor of the source coordinate; s0 < 0 marks "outside -> 0"
-};
-
-__device__ __forceinline__ double coord(double x, double z, double ma, double mb, double mc, double off) {
-    // (((0 + x*ma) + y*mb) + z*mc) + off with y*mb == +-0 for every y >= 0 (mb is +-0)
-    double c = __dadd_rn(0.0, __dmul_rn(x, ma));
-    c = __dadd_rn(c, __dmul_rn(0.0, mb));
-    c = __dadd_rn(c, __dmul_rn(z, mc));
-    return __dadd_rn(c, off);
-}
-
-__device__ __forceinline__ Cell make_cell(const RotParams& p, i64 x, i64 z, i64 W, i64 D) {
-    Cell c;
-    const double cc0 = coord((double)x, (double)z, p.m00, p.m01, p.m02, p.off0);
-    const double cc2 = coord((double)x, (double)z, p.m20, p.m21, p.m22, p.off2);
-    if (cc0 < 0.0 || cc0 > (double)(W - 1) || cc2 < 0.0 || cc2 > (double)(D - 1)) {
-        c.s0 = -1; c.s2 = 0; c.wx0 = c.wx1 = c.wz0 = c.wz1 = 0.0;
-        return c;
-    }
-    const double f0 = floor(cc0), f2 = floor(cc2);
-    c.s0 = (int)f0; c.s2 = (int)f2;
-    c.wx0 = __dsub_rn(1.0, __dsub_rn(cc0, f0));
-    c.wx1 = __dsub_rn(1.0, c.wx0);
-    c.wz0 = __dsub_rn(1.0, __dsub_rn(cc2, f2));
-    c.wz1 = __dsub_rn(1.0, c.wz0);
-    return c;
-}
 
 // value of one output voxel from plane y of `in`; taps with an exactly-zero weight add +0.0 and are
 // skipped (this also keeps the index in range: a tap beyond n-1 only ever occurs with weight 0).
@@ -137,23 +102,6 @@ __global__ __launch_bounds__(256) void k_rotate_generic(const u8* __restrict__ i
 // ------------------------------------------------------------------------------------------------
 constexpr int LT = 64;              // tile edge
 
-__device__ __forceinline__ u32 lut_of(const Cell& c) {
-    const double p00 = __dmul_rn(c.wx0, c.wz0), p01 = __dmul_rn(c.wx0, c.wz1), p10 = __dmul_rn(c.wx1, c.wz0),
-                 p11 = __dmul_rn(c.wx1, c.wz1);
-    u32 lut = 0;
-#pragma unroll
-    for (int b = 1; b < 16; ++b) {
-        double acc = 0.0;
-        if (b & 1) acc = __dadd_rn(acc, p00);
-        if (b & 2) acc = __dadd_rn(acc, p01);
-        if (b & 4) acc = __dadd_rn(acc, p10);
-        if (b & 8) acc = __dadd_rn(acc, p11);
-        // uint8 store rule: acc > 0 ? trunc(acc + 0.5) : 0 ; the weights sum to ~1 so the value is 0 or 1
-        if (acc > 0.0 && __dadd_rn(acc, 0.5) >= 1.0) lut |= 1u << b;
-    }
-    return lut;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Bit-sliced evaluation: EIGHT Y-planes per pass.  The source position of a cell is the same
 // in every plane, so the staged footprint holds, per source voxel, one byte whose bit p is the 0/1 value
@@ -165,7 +113,6 @@ __device__ __forceinline__ u32 lut_of(const Cell& c) {
 // (R >> p) & 0x01010101 is the output dword of plane p for the thread's 4 consecutive z.
 // Values > 1 anywhere raise *big_flag: the launcher lets the arithmetic kernel redo the step (see above).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 bsel(u32 sel, u32 a, u32 b) { return (sel & a) | (~sel & b); }   // v_bfi_b32
 
 __device__ __forceinline__ u32 lut_apply8(u32 lut, u32 t00, u32 t01, u32 t10, u32 t11) {
     u32 L[16];
@@ -368,15 +315,6 @@ __global__ __launch_bounds__(256) void k_rot_cells(RotParams p, i64 W, i64 D, Ce
     }
 }
 
-__device__ __forceinline__ u32 pperm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-// a[g].byte v  ->  v[v].byte g   (4 x 4 byte transpose)
-__device__ __forceinline__ void tr4x4(u32 a0, u32 a1, u32 a2, u32 a3, u32 v[4]) {
-    const u32 l01 = pperm(a1, a0, 0x05010400u), h01 = pperm(a1, a0, 0x07030602u);
-    const u32 l23 = pperm(a3, a2, 0x05010400u), h23 = pperm(a3, a2, 0x07030602u);
-    v[0] = pperm(l23, l01, 0x05040100u); v[1] = pperm(l23, l01, 0x07060302u);
-    v[2] = pperm(h23, h01, 0x05040100u); v[3] = pperm(h23, h01, 0x07060302u);
-}
-
 // bit q = mask_src[base + q] != 0 for q < np (all ones without a source mask): which planes of one source row are kept by the
 // 0-degree carve that process_voxel_grid folds into its first rotation step; masked planes are not even loaded
 __device__ __forceinline__ u32 src_plane_bits(const u8* __restrict__ mask_src, i64 base, int np) {
@@ -384,19 +322,6 @@ __device__ __forceinline__ u32 src_plane_bits(const u8* __restrict__ mask_src, i
     u32 bits = 0;
     for (int q = 0; q < np; ++q) bits |= (u32)(mask_src[base + q] != 0) << q;
     return bits;
-}
-
-__device__ __forceinline__ u32 lut_apply32(u32 lut, u32 t00, u32 t01, u32 t10, u32 t11) {
-    u32 L[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) L[k] = (u32)__builtin_amdgcn_sbfe((int)lut, k, 1);      // 0 or ~0 in one v_bfe_i32
-    u32 g[8], h[4];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = bsel(t00, L[2 * j + 1], L[2 * j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = bsel(t01, g[2 * j + 1], g[2 * j]);
-    const u32 m0 = bsel(t10, h[1], h[0]), m1 = bsel(t10, h[3], h[2]);
-    return bsel(t11, m1, m0);
 }
 
 constexpr int WPITCH = 128;                       // LDS row pitch in voxels (dwords)
@@ -1795,6 +1720,9 @@ int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 
     return PB3D_OK;
 }
 
+static int process_grid_impl(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D, const uint8_t* d_mask_wh,
+                             int angle_interval, uint8_t* d_out, uint8_t* d_tmp, int known_binary);
+
 extern "C" {
 
 int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
@@ -1811,6 +1739,18 @@ int pb3d_rotate_carve_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
 
 int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
                           const uint8_t* d_mask_wh, int angle_interval, uint8_t* d_out, uint8_t* d_tmp) {
+    return process_grid_impl(ctx, d_occ, W, H, D, d_mask_wh, angle_interval, d_out, d_tmp, 0);
+}
+
+}  // extern "C"
+
+int pb3d_process_grid_binary_dev(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
+                                 u8* d_tmp) {
+    return process_grid_impl(ctx, d_occ, W, H, D, d_mask_wh, angle_interval, d_out, d_tmp, 1);
+}
+
+static int process_grid_impl(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
+                             const uint8_t* d_mask_wh, int angle_interval, uint8_t* d_out, uint8_t* d_tmp, int known_binary) {
     PB3D_REQUIRE(ctx != nullptr, "pb3d_process_grid: null context");
     PB3D_REQUIRE(W >= 0 && H >= 0 && D >= 0, "pb3d_process_grid: bad shape");
     PB3D_REQUIRE(angle_interval > 0, "pb3d_process_grid: angle_interval must be a positive integer (got %d)", angle_interval);
@@ -1829,6 +1769,11 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     for (int k = 0; k < 9; ++k) ident = ident && M0[k] == ((k % 4 == 0) ? 1.0 : 0.0);
     PB3D_REQUIRE(ident, "pb3d_process_grid: internal error, Rinv(0) is not the identity");
     if (nsteps == 1) return pb3d_carve_mask_dev(ctx, d_occ, W, H, D, 1, d_mask_wh, d_out);
+    {   // chains of rotation steps stay bit-sliced between the steps (csrc/sliced.hip); data that is not 0 / 1 comes back here
+        int took = 0;
+        PB3D_TRY(pb3d_process_grid_sliced(ctx, d_occ, W, H, D, d_mask_wh, angle_interval, d_out, known_binary, &took));
+        if (took) return PB3D_OK;
+    }
     double M1[9], off1[3];
     PB3D_TRY(pb3d_rotinv(angle_interval, M1));
     PB3D_TRY(pb3d_offset(M1, shape, off1));
@@ -1862,5 +1807,3 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
     }
     return PB3D_OK;
 }
-
-}  // extern "C"

@@ -1,0 +1,396 @@
+// Chained rotation steps in a BIT-SLICED occupancy layout ("S32").
+//
+// process_voxel_grid (reference utils/voxel_carving_utils.py:104-126) rotates the already rotated and carved grid again and again:
+// range(0, 91, k) is 19 steps at the notebook's k = 5 (:193, notebook 1 cell 7).  On 0/1 occupancy every step is a table lookup on
+// four taps (rot_common.h: lut_of), and a Y-plane never mixes with another (the rotation is about Y), so between two steps the
+// volume does not have to be bytes at all:
+//
+//     S32[g][x][z]  (u32, pitch Dp = D rounded up to 8)      bit q = occ[x][32 g + q][z],   g < G = ceil(H / 32)
+//
+// is 1/8 byte per voxel, a middle step reads and writes 1/4 B/voxel instead of 2, and neither side converts anything: the staged
+// footprint of a tile IS the dword the 32-plane multiplexer tree wants, and the tree's result IS the dword that is stored.  The chain:
+//     k_s32_slice (u8 -> S32, the 0-degree carve folded in as a bit mask) -> k_s32_step per rotation -> k_s32_unslice (S32 -> u8)
+// plus ONE k_s32_prep launch that compiles every (step, tile) pair's "tile program" (LDS offsets + result tables of its 4096 cells,
+// the list of 16-byte units of its rotated footprint) from SciPy's f64 arithmetic.  The programs depend on (angles, W, D) only and
+// are cached across calls.  Data that is not 0/1 raises a flag in k_s32_slice: the caller then runs the byte chain (rotate.hip).
+#include "rot_common.h"
+
+namespace {
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_a1 __attribute__((aligned(1)));     // 8-byte access at any byte alignment (rows of odd-sized grids)
+
+constexpr int ST = 64;              // output tile edge (x and z)
+constexpr int STHREADS = 256;       // 16 cells per thread: 4 consecutive z in each of 4 rows
+constexpr int SROWS = 96;           // footprint rows in LDS (a rotated 64-tile spans <= 64 sqrt 2 + 2 = 92.6)
+constexpr int SPITCH = 97;          // LDS row pitch in dwords: ODD, so the 4 rows x 16 column groups a wave reads together hit 64 banks
+constexpr int SMAXU = 9;            // 16-byte units per thread: a full bounding box of 95 rows x 24 units
+constexpr int SMAXSTEPS = 32;       // steps per table build
+
+// the compiled form of one (step, tile): what a workgroup of k_s32_step needs besides the voxels
+struct STile {
+    int bx0, bz0, nrows, nunits, fits, pad0, pad1, pad2;
+    u32 ugoff[SMAXU * STHREADS];             // unit u: dword offset of its 4 voxels inside a plane group, (bx0 + r) * Dp + bz0 + 4 cu
+    unsigned short uloff[SMAXU * STHREADS];  // ... and inside the LDS footprint, r * SPITCH + 4 cu
+    u32 cellw[16 * STHREADS];                // [4 i + c][tid]: result table << 16 | LDS dword offset of tap (0,0); 0 = void cell
+};
+static_assert(sizeof(STile) % 16 == 0, "STile is read with 16-byte loads");
+
+struct StepParams { RotParams p[SMAXSTEPS]; };
+
+// bits[g * W + x]: bit q = mask_wh[x, 32 g + q] != 0 (zero for planes past H); also clears the chain's flag word
+__global__ __launch_bounds__(256) void k_s32_maskbits(const u8* __restrict__ mask_wh, i64 W, i64 H, int G, u32* __restrict__ bits, int* __restrict__ flag) {
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && flag) *flag = 0;
+    if (i >= (i64)G * W) return;
+    const i64 g = i / W, x = i - g * W, y0 = 32 * g;
+    u32 b = 0;
+    for (int q = 0; q < 32 && y0 + q < H; ++q) b |= (u32)(mask_wh[x * H + y0 + q] != 0) << q;
+    bits[i] = b;
+}
+
+// u8 (W,H,D) -> S32.  One thread = 8 consecutive z of one (g, x): 32 planes x 8 bytes in, 8 dwords out.  mbits (optional): the
+// 0-degree carve of process_voxel_grid (reference :111-124, first iteration) as a bit mask on the way in.
+__global__ __launch_bounds__(256) void k_s32_slice(const u8* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ mbits, i64 W, i64 H,
+                                                   i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total, int* __restrict__ flag) {
+    const u32 idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total) return;
+    const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
+    const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
+    const i64 z = 8 * (i64)zb;
+    const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
+    const u8* base = in + ((i64)x * H + 32 * (i64)g) * D + z;
+    const bool whole = z + 8 <= D;
+    u32 lo[32], hi[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        lo[q] = 0; hi[q] = 0;
+        if (q < np) {
+            if (whole) { const u32x2 v = *(const u32x2_a1*)(base + (i64)q * D); lo[q] = v.x; hi[q] = v.y; }
+            else {
+                for (int b = 0; b < 8 && z + b < D; ++b) {
+                    const u32 v = base[(i64)q * D + b];
+                    if (b < 4) lo[q] |= v << (8 * b); else hi[q] |= v << (8 * (b - 4));
+                }
+            }
+        }
+    }
+    u32 hib = 0, wl[4], wh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32 a = 0, b = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a |= lo[8 * k + q] << q; b |= hi[8 * k + q] << q; hib |= lo[8 * k + q] | hi[8 * k + q]; }
+        wl[k] = a; wh[k] = b;
+    }
+    u32 vl[4], vh[4];
+    tr4x4(wl[0], wl[1], wl[2], wl[3], vl);      // vl[c]: byte k = planes 8 k .. 8 k + 7 of voxel z + c
+    tr4x4(wh[0], wh[1], wh[2], wh[3], vh);
+    const u32 m = mbits ? mbits[row] : 0xffffffffu;
+    u32x4 o0, o1;
+    o0.x = vl[0] & m; o0.y = vl[1] & m; o0.z = vl[2] & m; o0.w = vl[3] & m;
+    o1.x = vh[0] & m; o1.y = vh[1] & m; o1.z = vh[2] & m; o1.w = vh[3] & m;
+    u32* op = out + (i64)row * Dp + z;
+    *(u32x4*)op = o0;
+    *(u32x4*)(op + 4) = o1;
+    // a value other than 0 / 1: the chain cannot represent it (one relaxed look first: on such data every thread would hit the word)
+    if ((hib & 0xfefefefeu) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
+}
+
+// S32 -> u8 (W,H,D): the inverse, same thread shape
+__global__ __launch_bounds__(256) void k_s32_unslice(const u32* __restrict__ in, u8* __restrict__ out, i64 W, i64 H, i64 D, i64 Dp, pb3d_magic mzb,
+                                                     pb3d_magic mw, u32 total) {
+    const u32 idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total) return;
+    const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
+    const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
+    const i64 z = 8 * (i64)zb;
+    const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
+    const u32* ip = in + (i64)row * Dp + z;
+    const u32x4 a = *(const u32x4*)ip, b = *(const u32x4*)(ip + 4);
+    u32 vl[4], vh[4];
+    tr4x4(a.x, a.y, a.z, a.w, vl);               // vl[k]: byte c = planes 8 k .. 8 k + 7 of voxel z + c
+    tr4x4(b.x, b.y, b.z, b.w, vh);
+    u8* base = out + ((i64)x * H + 32 * (i64)g) * D + z;
+    const bool whole = z + 8 <= D;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q >= np) break;
+        u32x2 v;
+        v.x = (vl[q >> 3] >> (q & 7)) & 0x01010101u; v.y = (vh[q >> 3] >> (q & 7)) & 0x01010101u;
+        u8* dp = base + (i64)q * D;
+        if (whole) *(u32x2_a1*)dp = v;
+        else
+            for (int bb = 0; bb < 8 && z + bb < D; ++bb) dp[bb] = (u8)((bb < 4 ? v.x : v.y) >> (8 * (bb & 3)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Tile programs.  One workgroup per (step, tile): every thread evaluates SciPy's coordinates, weights and result table of its 16
+// cells ONCE (f64, no contraction), the workgroup finds the bounding rows / per-row column extents of the taps (a rotated tile is
+// a diamond inside its bounding box), lays the rows out in LDS and lists the 16-byte units to stage.
+// Thread tid owns cells (x0 + (tid >> 4) + 16 i, z0 + 4 (tid & 15) + c), i, c < 4: a wave's 64 lanes cover 4 rows x 64 z, so each of
+// its stores writes four whole 256-byte row segments.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(STHREADS) void k_s32_prep(StepParams sp, i64 W, i64 D, i64 Dp, int ntz, STile* __restrict__ tiles) {
+    __shared__ int bb[4];
+    __shared__ int rmin[SROWS], rmax[SROWS];
+    __shared__ int ustart[SROWS + 1];
+    __shared__ int rc0[SROWS];
+    const int tid = threadIdx.x;
+    const RotParams p = sp.p[blockIdx.y];
+    const int t = (int)blockIdx.x;
+    STile* o = tiles + (i64)blockIdx.y * gridDim.x + t;
+    const i64 x0 = (i64)(t / ntz) * ST, z0 = (i64)(t % ntz) * ST;
+    if (tid == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+    if (tid < SROWS) { rmin[tid] = 0x7fffffff; rmax[tid] = -1; }
+    __syncthreads();
+    const int tz = tid & 15, jr = tid >> 4;
+    int s0[16], s2[16];
+    u32 lut[16];                    // bits 0..15 table, 16: x tap 1 used, 17: z tap 1 used
+    int mn0 = 0x7fffffff, mx0 = -1, mn2 = 0x7fffffff, mx2 = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * i + c;
+            const i64 x = x0 + jr + 16 * i, z = z0 + 4 * tz + c;
+            s0[k] = -1; s2[k] = 0; lut[k] = 0;
+            if (x < W && z < D) {
+                const Cell cl = make_cell(p, x, z, W, D);
+                if (cl.s0 >= 0) {
+                    s0[k] = cl.s0; s2[k] = cl.s2;
+                    lut[k] = lut_of(cl) | (cl.wx1 != 0.0 ? 1u << 16 : 0u) | (cl.wz1 != 0.0 ? 1u << 17 : 0u);
+                    const int e0 = cl.s0 + (int)((lut[k] >> 16) & 1u), e2 = cl.s2 + (int)((lut[k] >> 17) & 1u);
+                    mn0 = min(mn0, cl.s0); mx0 = max(mx0, e0); mn2 = min(mn2, cl.s2); mx2 = max(mx2, e2);
+                }
+            }
+        }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        mn0 = min(mn0, __shfl_xor(mn0, s)); mx0 = max(mx0, __shfl_xor(mx0, s));
+        mn2 = min(mn2, __shfl_xor(mn2, s)); mx2 = max(mx2, __shfl_xor(mx2, s));
+    }
+    if ((tid & 63) == 0 && mx0 >= 0) { atomicMin(&bb[0], mn0); atomicMax(&bb[1], mx0); atomicMin(&bb[2], mn2); atomicMax(&bb[3], mx2); }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1], bz0 = bb[2] & ~3, bz1 = bb[3];      // columns start on a 16-byte boundary
+    const bool any_valid = bx1 >= 0;
+    const int nrows = any_valid ? bx1 - bx0 + 1 : 0;
+    // + 1: the second tap of a cell is read from LDS even when its weight is 0 (the table ignores it) -- it must stay inside the array
+    bool fits = !any_valid || (nrows + 1 <= SROWS && bz1 - bz0 + 2 <= SPITCH);
+    if (fits && any_valid) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (s0[k] < 0) continue;
+            const int r = s0[k] - bx0, e2 = s2[k] + (int)((lut[k] >> 17) & 1u);
+            atomicMin(&rmin[r], s2[k]); atomicMax(&rmax[r], e2);
+            if ((lut[k] >> 16) & 1u) { atomicMin(&rmin[r + 1], s2[k]); atomicMax(&rmax[r + 1], e2); }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                    // wave 0: exclusive scan of the per-row unit counts (rows tid and tid + 64)
+        int n[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = tid + 64 * h;
+            n[h] = 0;
+            if (r < SROWS) {
+                rc0[r] = 0;
+                if (r < nrows && fits && rmax[r] >= 0) {
+                    rc0[r] = (rmin[r] - bz0) >> 2;
+                    n[h] = ((rmax[r] - bz0) >> 2) - ((rmin[r] - bz0) >> 2) + 1;
+                }
+            }
+        }
+        int inc0 = n[0], inc1 = n[1];
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int a = __shfl_up(inc0, s), b2 = __shfl_up(inc1, s);
+            if (tid >= s) { inc0 += a; inc1 += b2; }
+        }
+        const int tot0 = __shfl(inc0, 63);
+        ustart[tid] = inc0 - n[0];
+        if (tid + 64 <= SROWS) ustart[tid + 64] = tot0 + inc1 - n[1];
+    }
+    __syncthreads();
+    int nunits = (any_valid && fits) ? ustart[SROWS] : 0;
+    if (nunits > SMAXU * STHREADS) { fits = false; nunits = 0; }
+    if (fits && tid < nrows) {
+        const int u0 = ustart[tid], u1 = ustart[tid + 1];
+        for (int u = u0; u < u1; ++u) {
+            const int cu = rc0[tid] + (u - u0);
+            o->ugoff[u] = (u32)(((i64)bx0 + tid) * Dp + bz0 + 4 * cu);
+            o->uloff[u] = (unsigned short)(tid * SPITCH + 4 * cu);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        u32 w = 0;
+        if (fits && s0[k] >= 0) w = (lut[k] << 16) | (u32)((s0[k] - bx0) * SPITCH + (s2[k] - bz0));
+        o->cellw[k * STHREADS + tid] = w;
+    }
+    if (tid == 0) { o->bx0 = bx0; o->bz0 = bz0; o->nrows = nrows; o->nunits = nunits; o->fits = fits ? 1 : 0; o->pad0 = o->pad1 = o->pad2 = 0; }
+}
+
+// One rotation step S32 -> S32 with the step's mask (reference :116-124 for one angle).  Workgroup = (tile, chunk of plane groups);
+// all tiles of a chunk run on ONE XCD (blockIdx % 8), so the lines neighbouring footprints share meet in one L2.
+// Per plane group: stage the footprint (<= SMAXU 16-byte loads per thread, plain dword copies -- nothing is converted), evaluate
+// 16 cells x 32 planes (four LDS dwords + a 15-select multiplexer tree per cell), store 4 x 16 bytes.
+__global__ __launch_bounds__(STHREADS, 4) void k_s32_step(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ mbits,
+                                                           const STile* __restrict__ tiles, i64 W, i64 Dp, int G, int ntz, int ntiles, int gpw,
+                                                           int nchunks) {
+    __shared__ u32 tile[SROWS * SPITCH];
+    const int tid = threadIdx.x;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int t = slot % ntiles;
+    const int chunk = (slot / ntiles) * 8 + (int)(blockIdx.x & 7u);
+    if (chunk >= nchunks) return;                      // whole workgroup, before any barrier
+    const STile* ti = tiles + t;
+    const i64 x0 = (i64)(t / ntz) * ST, z0 = (i64)(t % ntz) * ST;
+    const int g_beg = chunk * gpw, g_end = g_beg + gpw < G ? g_beg + gpw : G;
+    const int nunits = ti->nunits;
+    u32 ug[SMAXU], ul[SMAXU];
+#pragma unroll
+    for (int j = 0; j < SMAXU; ++j) {
+        const int u = tid + STHREADS * j;
+        ug[j] = 0xffffffffu; ul[j] = 0;
+        if (u < nunits) { ug[j] = ti->ugoff[u]; ul[j] = ti->uloff[u]; }
+    }
+    u32 cw[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cw[i] = ti->cellw[i * STHREADS + tid];
+    const int tz = tid & 15, jr = tid >> 4;
+    const i64 zc = z0 + 4 * tz;
+    const bool zok = zc < Dp;
+    for (int g = g_beg; g < g_end; ++g) {
+        const u32* src = in + (i64)g * W * Dp;
+        u32x4 v[SMAXU];
+#pragma unroll
+        for (int j = 0; j < SMAXU; ++j)
+            if (ug[j] != 0xffffffffu) v[j] = *(const u32x4*)(src + ug[j]);
+#pragma unroll
+        for (int j = 0; j < SMAXU; ++j)
+            if (ug[j] != 0xffffffffu) { u32* d = tile + ul[j]; d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32 R[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32 w = cw[4 * i + c];
+                const u32* tp = tile + (w & 0xffffu);
+                R[c] = lut_apply32(w >> 16, tp[0], tp[1], tp[SPITCH], tp[SPITCH + 1]);
+            }
+            const i64 x = x0 + jr + 16 * i;
+            if (x < W && zok) {
+                const u32 m = mbits[(i64)g * W + x];
+                u32x4 r; r.x = R[0] & m; r.y = R[1] & m; r.z = R[2] & m; r.w = R[3] & m;
+                *(u32x4*)(out + ((i64)g * W + x) * Dp + zc) = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// every step of the chain is a rotation whose 64-tile footprint fits the LDS box by geometry (no device-side fallback is needed)
+static bool step_fits(const double M[9]) {
+    const double ext0 = fabs(M[0]) + fabs(M[2]), ext2 = fabs(M[6]) + fabs(M[8]);
+    return ext0 <= 1.4143 && ext2 <= 1.4143;
+}
+
+}  // namespace
+
+// process_voxel_grid(occ, mask, angle_interval) (reference utils/voxel_carving_utils.py:104-126) through the bit-sliced chain.
+// *took = 0: the chain does not apply (fewer than two rotation steps, shape limits, tuning, or -- unless known_binary -- data that
+// is not 0/1): nothing was written and the caller runs the byte chain.  known_binary = 0 costs one host wait for the slice kernel.
+int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
+                             int known_binary, int* took) {
+    *took = 0;
+    const int nsteps = 90 / angle_interval + 1;
+    const int nrot = nsteps - 1;
+    // (a pinned byte-tile kernel -- the parity tests pin each of them in turn -- means the byte chain)
+    if (ctx->tune_sliced == 1 || ctx->tune_rotate_tile != 0 || nrot < (ctx->tune_sliced == 2 ? 1 : 2)) return PB3D_OK;
+    const i64 Dp = (D + 7) & ~(i64)7;
+    const int G = (int)((H + 31) / 32);
+    const i64 nzb = Dp / 8;
+    if (W >= 32768 || D >= 32768 || (i64)G * W * nzb >= (1ll << 31) || W * Dp >= (1ll << 31)) return PB3D_OK;
+    const i64 shape[3] = {W, H, D};
+    StepParams sp;
+    const int ntz = (int)((D + ST - 1) / ST), ntx = (int)((W + ST - 1) / ST), ntiles = ntz * ntx;
+    void *flagp, *mb;
+    PB3D_TRY(pb3d_scratch(ctx, 34, 64, &flagp));
+    PB3D_TRY(pb3d_scratch(ctx, 35, (size_t)G * W * sizeof(u32), &mb));
+    int* flag = (int*)flagp;
+    const size_t sbytes = (size_t)G * W * Dp * sizeof(u32);
+    void *A = nullptr, *B = nullptr;
+    PB3D_TRY(pb3d_dev_alloc(ctx, sbytes, &A));
+    int rc = pb3d_dev_alloc(ctx, sbytes, &B);
+    if (rc != PB3D_OK) { (void)pb3d_dev_free(ctx, A); return rc; }
+    auto body = [&]() -> int {
+        hipLaunchKernelGGL(k_s32_maskbits, dim3((unsigned)(((i64)G * W + 255) / 256)), dim3(256), 0, ctx->stream, d_mask_wh, W, H, G, (u32*)mb, flag);
+        const u32 total = (u32)((i64)G * W * nzb);
+        const pb3d_magic mzb = pb3d_make_magic((u32)nzb), mw = pb3d_make_magic((u32)W);
+        hipLaunchKernelGGL(k_s32_slice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, (const u32*)mb, W, H, D, Dp, mzb, mw,
+                           total, flag);
+        PB3D_CHECK_LAUNCH();
+        int* hflag = (int*)((char*)ctx->pinned + ctx->pinned_bytes - 64);
+        if (!known_binary) {
+            PB3D_HIP(hipMemcpyAsync(hflag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PB3D_HIP(hipEventRecord(ctx->s32_ev, ctx->stream));
+        }
+        int gpw = ctx->tune_s32_gpw > 0 ? ctx->tune_s32_gpw : 1;
+        if (ctx->tune_s32_gpw <= 0)
+            while (gpw < G && (i64)ntiles * ((G + gpw - 1) / gpw) > (i64)ctx->cus * 16) ++gpw;
+        const int nchunks = (G + gpw - 1) / gpw;
+        const i64 nblk = 8ll * ntiles * ((nchunks + 7) / 8);
+        PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_process_grid: grid too large");
+        u32 *src = (u32*)A, *dst = (u32*)B;
+        bool checked = known_binary != 0;
+        for (int s0 = 0; s0 < nrot; s0 += SMAXSTEPS) {
+            const int ns = nrot - s0 < SMAXSTEPS ? nrot - s0 : SMAXSTEPS;
+            memset(&sp, 0, sizeof(sp));
+            for (int k = 0; k < ns; ++k) {
+                double M[9], off[3];
+                PB3D_TRY(pb3d_rotinv((s0 + k + 1) * angle_interval, M));
+                PB3D_TRY(pb3d_offset(M, shape, off));
+                if (!step_fits(M)) return PB3D_EUNSUPPORTED;            // (never: every Rinv is a rotation)
+                sp.p[k] = RotParams{M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+            }
+            // the tile programs of this run of steps: where an earlier call left them, or built now
+            void* tp;
+            PB3D_TRY(pb3d_scratch(ctx, 32, (size_t)ns * ntiles * sizeof(STile), &tp));
+            pb3d_ctx::S32Cache& sc = ctx->s32_cache;
+            const bool hit = ctx->tune_misc[4] != 1 && sc.valid && sc.gen == ctx->scratch_gen && sc.W == W && sc.D == D && sc.ns == ns &&
+                             memcmp(sc.p, sp.p, sizeof(RotParams) * (size_t)ns) == 0;
+            if (!hit) {
+                sc.valid = false;
+                hipLaunchKernelGGL(k_s32_prep, dim3((unsigned)ntiles, (unsigned)ns), dim3(STHREADS), 0, ctx->stream, sp, W, D, Dp, ntz, (STile*)tp);
+                PB3D_CHECK_LAUNCH();
+                static_assert(sizeof(sc.p) == sizeof(sp.p), "S32Cache holds one StepParams");
+                memcpy(sc.p, sp.p, sizeof(sp.p));
+                sc.W = W; sc.D = D; sc.ns = ns; sc.gen = ctx->scratch_gen; sc.valid = nrot <= SMAXSTEPS;
+            }
+            if (!checked) {                                            // the slice kernel's verdict (the table build is queued behind it meanwhile)
+                PB3D_HIP(hipEventSynchronize(ctx->s32_ev));
+                checked = true;
+                if (*hflag != 0) return PB3D_EUNSUPPORTED;
+            }
+            for (int k = 0; k < ns; ++k) {
+                hipLaunchKernelGGL(k_s32_step, dim3((unsigned)nblk), dim3(STHREADS), 0, ctx->stream, (const u32*)src, dst, (const u32*)mb,
+                                   (const STile*)tp + (i64)k * ntiles, W, Dp, G, ntz, ntiles, gpw, nchunks);
+                u32* t2 = src; src = dst; dst = t2;
+            }
+            PB3D_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(k_s32_unslice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, W, H, D, Dp, mzb, mw, total);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    };
+    rc = body();
+    (void)pb3d_dev_free(ctx, A);          // (the blocks go back to the context's pool; the stream is in order)
+    (void)pb3d_dev_free(ctx, B);
+    if (rc == PB3D_EUNSUPPORTED) return PB3D_OK;          // not 0/1 data: *took stays 0
+    if (rc == PB3D_OK) *took = 1;
+    return rc;
+}

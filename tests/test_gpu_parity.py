@@ -595,6 +595,44 @@ def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
                     assert np.array_equal(got, want), (W, H, D, ai, tile, int((got != want).sum()))
 
 
+def test_sliced_chain_equals_byte_chain_equals_oracle(pb3d_gpu, oracle):
+    """chains of rotation steps stay bit-sliced between the steps (csrc/sliced.hip: 32 planes per dword, 1/4 B/voxel per middle
+    step): sliced chain == byte chain == oracle on 0/1 grids, on 0..255 grids (the slice kernel's flag sends those to the byte
+    chain) and on odd-sized grids; masks of every density; single-step calls with the sliced form forced."""
+    rng = np.random.default_rng(31)
+    shapes = [(64, 40, 64), (37, 11, 37), (130, 70, 131), (96, 33, 72), (200, 64, 256), (3, 5, 2), (1, 1, 1), (65, 32, 9), (16, 95, 257)]
+    for (W, H, D) in shapes:
+        for ai in (5, 45, 30, 7, 18):
+            for kind in ("binary", "bytes", "dense"):
+                if kind == "binary":
+                    g = (rng.random((W, H, D)) < 0.6).astype(np.uint8)
+                elif kind == "dense":
+                    g = np.ones((W, H, D), np.uint8)
+                else:
+                    g = rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+                m = rng.random((H, W)) < (0.9 if kind != "dense" else 0.97)
+                want = oracle.process_voxel_grid(g, m, ai)
+                for sliced in (0, 1):
+                    pb3d_gpu._lib.set_tuning("sliced", sliced)
+                    try:
+                        got = pb3d_gpu.process_voxel_grid(g, m, ai)
+                    finally:
+                        pb3d_gpu._lib.set_tuning("sliced", 0)
+                    assert np.array_equal(got, want), (W, H, D, ai, kind, sliced, int((got != want).sum()))
+    # one rotation step through the sliced kernels (forced): 90 degrees (even and odd W + D), 60 degrees
+    for (W, H, D) in [(64, 40, 64), (37, 11, 38), (130, 70, 131), (128, 33, 128)]:
+        g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
+        m = rng.random((H, W)) < 0.9
+        for ai in (90, 60):
+            want = oracle.process_voxel_grid(g, m, ai)
+            pb3d_gpu._lib.set_tuning("sliced", 2)
+            try:
+                got = pb3d_gpu.process_voxel_grid(g, m, ai)
+            finally:
+                pb3d_gpu._lib.set_tuning("sliced", 0)
+            assert np.array_equal(got, want), (W, H, D, ai, int((got != want).sum()))
+
+
 def test_packed_kernel_odd_rows_with_dirty_slack(pb3d_gpu, oracle):
     """rows that are not multiples of 16 bytes: the packed generic-angle kernel reads whole 16-byte units, the last one of the volume up
     to 15 bytes into the allocation's slack.  Whatever lies there (here: 0xff) must neither change a voxel nor send the step to the
