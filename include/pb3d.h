@@ -249,6 +249,16 @@ int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
                             const int64_t hi[3], uint8_t* d_occ);
 int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
                              int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved);
+/* The whole component loop of left_right_guided_carve (reference utils/voxel_carving_utils.py:178-201) in one call, IN PLACE on the
+ * resident colour grid: for component k + 1 of d_labels with box bbox_lo_hi[6k..] (lo inclusive, hi exclusive) and crop mask
+ * masks[mask_off[k] ..] ((Wc,Hc) uint8 truthiness, host memory, mask_bytes in all) the crop's occupancy goes through
+ * process_voxel_grid(., crop mask, angle_interval) and the component's voxels that do not survive are cleared; carved_counts[k] (host)
+ * = the log's "carved voxels" (:195).  One launch pair per batch of components (all 32-plane slices of all crops resident in LDS for
+ * every rotation step).  *took = 0 (nothing done): a crop's slice does not fit the LDS -- run the per-component entries below.
+ * The call returns after the device has finished (the counts are host values). */
+int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
+                          const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
+                          int64_t* carved_counts, int* took);
 /* *d_count (a device int64 the caller has zeroed) += number of non-zero bytes of d_bytes[0..n): the "carved voxels" figure of
  * left_right_guided_carve's log (reference utils/voxel_carving_utils.py:197), without a host round trip per component. */
 int pb3d_count_nonzero_dev(pb3d_ctx* ctx, const uint8_t* d_bytes, int64_t n, int64_t* d_count);

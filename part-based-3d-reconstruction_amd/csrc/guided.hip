@@ -1,0 +1,272 @@
+// N1: the component loop of left_right_guided_carve (reference utils/voxel_carving_utils.py:178-201) as ONE launch sequence.
+//
+// Per 3-D component the reference crops the bounding box, takes the crop's occupancy, runs process_voxel_grid on it with the part's
+// own angle step (19 steps at the notebook's angle 5; crops are 31 x 189 x 31 ... 99 x 116 x 99 at Taj 512), clears the component and
+// pastes what survives.  Launched step by step that is ~20 tiny kernels per component.  But a Y-plane never mixes with another in
+// the whole chain (every rotation is about Y, the mask is per (x,y)), and 32 bit-sliced planes of a crop are one dword per (x,z)
+// cell -- 40 KB for the dome: a workgroup keeps its 32 planes in LDS for ALL steps.  So, per batch of components:
+//     k_crop_cells   the result table + source offset of every (component, step, cell) from SciPy's f64 arithmetic (rot_common.h)
+//     k_crop_chain   one workgroup per (component, 32 planes): occupancy of the crop from the colour grid -> bit-sliced in LDS ->
+//                    0-degree carve (mask bits) -> every rotation step LDS -> LDS -> count the survivors (the log's "carved
+//                    voxels") and clear the component's voxels that did not survive, IN PLACE.
+// In place is exact: a paste only ever writes colored[v] back where it already is, or 0 on the component's own voxels (:197-201).
+// Components whose boxes overlap interact through the ORIGINAL grid (a later crop sees an earlier component's voxels): those are
+// put in consecutive batches that read a copy taken before the first write.
+#include <vector>
+
+#include "rot_common.h"
+
+namespace {
+
+struct CropDesc {
+    int x0, y0, z0, Wc, Hc, Dc, id, g0, ng, pitch;
+    u32 mask_off, cell_off;
+    int pad[4];
+};
+static_assert(sizeof(CropDesc) == 64, "CropDesc is 64 bytes");
+
+constexpr int GTHREADS = 512;
+constexpr int kMaxLds = 150 * 1024;
+
+// celltab[cell_off + s * ncell + cell] = table << 16 | LDS offset of tap (0,0); 0 = void cell
+__global__ __launch_bounds__(256) void k_crop_cells(const CropDesc* __restrict__ descs, const RotParams* __restrict__ params, int nrot,
+                                                    u32* __restrict__ celltab) {
+    const int comp = (int)blockIdx.y / nrot, s = (int)blockIdx.y - comp * nrot;
+    const CropDesc d = descs[comp];
+    const RotParams p = params[blockIdx.y];
+    const int ncell = d.Wc * d.Dc;
+    for (int cell = (int)blockIdx.x * 256 + (int)threadIdx.x; cell < ncell; cell += (int)gridDim.x * 256) {
+        const int xs = cell / d.Dc, zs = cell - xs * d.Dc;
+        const Cell c = make_cell(p, xs, zs, d.Wc, d.Dc);
+        u32 w = 0;
+        if (c.s0 >= 0) w = (lut_of(c) << 16) | (u32)(c.s0 * d.pitch + c.s2);
+        celltab[(i64)d.cell_off + (i64)s * ncell + cell] = w;
+    }
+}
+
+// src and dst may be the same volume (no __restrict__): a workgroup reads its crop's planes before it clears anything in them, and no
+// other workgroup of the launch touches those voxels (disjoint boxes within a batch, disjoint planes within a component).
+__global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* dst_rgb, const int* __restrict__ labels, i64 H, i64 D,
+                                                         const CropDesc* __restrict__ descs, int ncomp, const u8* __restrict__ masks,
+                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore) {
+    extern __shared__ u32 lds[];
+    const int tid = threadIdx.x;
+    int c = 0;
+    while (c + 1 < ncomp && descs[c + 1].g0 <= (int)blockIdx.x) ++c;        // uniform
+    const CropDesc d = descs[c];
+    const int g = (int)blockIdx.x - d.g0;
+    const int Wc = d.Wc, Dc = d.Dc, pitch = d.pitch;
+    const int plane = (Wc + 1) * pitch + 1;
+    u32* A = lds;
+    u32* B = lds + plane;
+    u32* mb = lds + 2 * plane;
+    const int np = d.Hc - 32 * g < 32 ? d.Hc - 32 * g : 32;
+    const int ncell = Wc * Dc;
+    for (int xs = tid; xs < Wc; xs += GTHREADS) {
+        const u8* mp = masks + d.mask_off + (i64)xs * d.Hc + 32 * g;
+        u32 b = 0;
+        for (int q = 0; q < np; ++q) b |= (u32)(mp[q] != 0) << q;
+        mb[xs] = b;
+    }
+    __syncthreads();
+    // this thread's cells: tid, tid + 512, ... -- (xs, zs) advanced without a division per cell
+    const int dx = GTHREADS / Dc, dz = GTHREADS - dx * Dc;
+    const int xs0 = tid / Dc, zs0 = tid - xs0 * Dc;
+    const i64 rowb = D * 3;                              // bytes from plane y to plane y + 1 of the grid
+    {   // occupancy of the crop (any channel > 0, reference :190), 32 planes per cell, with the 0-degree carve (:124, first iteration)
+        int xs = xs0, zs = zs0;
+        for (int cell = tid; cell < ncell; cell += GTHREADS) {
+            const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * 3;
+            u32 bits = 0;
+            for (int q = 0; q < np; ++q) { const u8* v = p + (i64)q * rowb; bits |= (u32)((v[0] | v[1] | v[2]) != 0) << q; }
+            A[xs * pitch + zs] = bits & mb[xs];
+            xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
+        }
+    }
+    __syncthreads();
+    for (int s = 0; s < nrot; ++s) {
+        const u32* ct = celltab + (i64)d.cell_off + (i64)s * ncell;
+        int xs = xs0, zs = zs0;
+        for (int cell = tid; cell < ncell; cell += GTHREADS) {
+            const u32 w = ct[cell];
+            const u32* tp = A + (w & 0xffffu);
+            B[xs * pitch + zs] = lut_apply32(w >> 16, tp[0], tp[1], tp[pitch], tp[pitch + 1]) & mb[xs];
+            xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
+        }
+        __syncthreads();
+        u32* t2 = A; A = B; B = t2;
+    }
+    // survivors: count them, and clear the component's own voxels that are not among them (reference :195-201)
+    unsigned long long cnt = 0;
+    {
+        const u32 live = np == 32 ? 0xffffffffu : ((1u << np) - 1u);
+        int xs = xs0, zs = zs0;
+        for (int cell = tid; cell < ncell; cell += GTHREADS) {
+            const u32 R = A[xs * pitch + zs];
+            cnt += (unsigned long long)__popc(R);
+            const i64 v0 = ((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs;
+            for (u32 todo = ~R & live; todo; todo &= todo - 1) {
+                const i64 v = v0 + (i64)__builtin_ctz(todo) * D;
+                if (labels[v] == d.id) { u8* o = dst_rgb + 3 * v; o[0] = 0; o[1] = 0; o[2] = 0; }
+            }
+            if (restore) {          // boxes overlap somewhere: an EARLIER component may have cleared a voxel this crop keeps -- write it back (:200-201)
+                for (u32 kept = R & live; kept; kept &= kept - 1) {
+                    const i64 v = v0 + (i64)__builtin_ctz(kept) * D;
+                    const u8* sv = src_rgb + 3 * v;
+                    if (sv[0] | sv[1] | sv[2]) { u8* o = dst_rgb + 3 * v; o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2]; }
+                }
+            }
+            xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&counts[d.id - 1], cnt);
+}
+
+static bool boxes_overlap(const i64* a, const i64* b) {
+    return a[0] < b[3] && b[0] < a[3] && a[1] < b[4] && b[1] < a[4] && a[2] < b[5] && b[2] < a[5];
+}
+
+}  // namespace
+
+extern "C" {
+
+int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
+                          const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
+                          int64_t* carved_counts, int* took) {
+    PB3D_REQUIRE(ctx && took && W >= 0 && H >= 0 && D >= 0 && ncomp >= 0, "pb3d_guided_carve: bad argument");
+    *took = 0;
+    PB3D_REQUIRE(angle_interval > 0, "pb3d_guided_carve: angle_interval must be a positive integer (got %d)", angle_interval);
+    if (ncomp == 0 || W * H * D == 0) { *took = 1; return PB3D_OK; }
+    PB3D_REQUIRE(d_grid_rgb && d_labels && bbox_lo_hi && masks && mask_off && carved_counts, "pb3d_guided_carve: null buffer");
+    const int nrot = 90 / angle_interval;                 // len(range(0, 91, k)) - 1 rotation steps after the 0-degree carve
+    // every crop's 32-plane slice (two buffers + mask bits) must fit the LDS and its offsets 16 bits: otherwise the caller's loop
+    size_t lds_max = 0;
+    i64 ncells_total = 0;
+    for (i64 k = 0; k < ncomp; ++k) {
+        const i64* b = bbox_lo_hi + 6 * k;
+        const i64 Wc = b[3] - b[0], Hc = b[4] - b[1], Dc = b[5] - b[2];
+        PB3D_REQUIRE(b[0] >= 0 && b[1] >= 0 && b[2] >= 0 && b[3] <= W && b[4] <= H && b[5] <= D && Wc > 0 && Hc > 0 && Dc > 0,
+                     "pb3d_guided_carve: box outside the grid");
+        PB3D_REQUIRE(mask_off[k] >= 0 && mask_off[k] + Wc * Hc <= mask_bytes, "pb3d_guided_carve: mask outside the buffer");
+        const i64 pitch = Dc | 1, plane = (Wc + 1) * pitch + 1;
+        if (plane >= 65536) return PB3D_OK;
+        const size_t lds = (size_t)(2 * plane + Wc) * sizeof(u32);
+        if (lds > (size_t)kMaxLds) return PB3D_OK;
+        lds_max = lds > lds_max ? lds : lds_max;
+        ncells_total += Wc * Dc;
+    }
+    if (!ctx->guided_lds_set) {
+        PB3D_HIP(hipFuncSetAttribute((const void*)k_crop_chain, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        ctx->guided_lds_set = true;
+    }
+    const size_t nvox3 = (size_t)(W * H * D) * 3;
+    void *d_masks, *d_counts;
+    PB3D_TRY(pb3d_scratch(ctx, 37, (size_t)mask_bytes + 16, &d_masks));
+    PB3D_TRY(pb3d_scratch(ctx, 39, (size_t)ncomp * sizeof(unsigned long long), &d_counts));
+    PB3D_HIP(hipMemcpyAsync(d_masks, masks, (size_t)mask_bytes, hipMemcpyHostToDevice, ctx->stream));
+    PB3D_HIP(hipMemsetAsync(d_counts, 0, (size_t)ncomp * sizeof(unsigned long long), ctx->stream));
+    // batches: consecutive components with pairwise disjoint boxes, at most kBatch of them (descriptor upload size)
+    const int kBatch = 48;
+    std::vector<std::pair<i64, i64>> batches;
+    for (i64 a = 0; a < ncomp;) {
+        i64 e = a + 1;
+        for (; e < ncomp && e - a < kBatch; ++e) {
+            bool hit = false;
+            for (i64 j = a; j < e && !hit; ++j) hit = boxes_overlap(bbox_lo_hi + 6 * j, bbox_lo_hi + 6 * e);
+            if (hit) break;
+        }
+        batches.push_back({a, e});
+        a = e;
+    }
+    // do ANY two boxes overlap?  Then later crops must see the grid as it was: read a copy.
+    bool any_overlap = false;
+    for (i64 i = 0; i < ncomp && !any_overlap; ++i)
+        for (i64 j = i + 1; j < ncomp && !any_overlap; ++j) any_overlap = boxes_overlap(bbox_lo_hi + 6 * i, bbox_lo_hi + 6 * j);
+    void* copy = nullptr;
+    if (any_overlap) {
+        PB3D_TRY(pb3d_dev_alloc(ctx, nvox3, &copy));
+        hipError_t e = hipMemcpyAsync(copy, d_grid_rgb, nvox3, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) { (void)pb3d_dev_free(ctx, copy); PB3D_HIP(e); }
+    }
+    std::vector<CropDesc> hd;
+    std::vector<RotParams> hp;
+    // host staging of every batch stays alive until the final synchronisation below
+    std::vector<std::vector<CropDesc>> keep_d;
+    std::vector<std::vector<RotParams>> keep_p;
+    keep_d.reserve(batches.size()); keep_p.reserve(batches.size());
+    int rc = PB3D_OK;
+    auto run = [&]() -> int {
+        size_t desc_bytes = 0, par_bytes = 0, tab_bytes = 0;
+        for (auto& be : batches) {
+            size_t cells = 0;
+            for (i64 k = be.first; k < be.second; ++k) { const i64* b = bbox_lo_hi + 6 * k; cells += (size_t)((b[3] - b[0]) * (b[5] - b[2])); }
+            const size_t n = (size_t)(be.second - be.first);
+            desc_bytes = std::max(desc_bytes, n * sizeof(CropDesc));
+            par_bytes = std::max(par_bytes, n * (size_t)(nrot > 0 ? nrot : 1) * sizeof(RotParams));
+            tab_bytes = std::max(tab_bytes, cells * (size_t)(nrot > 0 ? nrot : 1) * sizeof(u32));
+        }
+        void *dd, *dp, *dt;
+        // one region per batch would let the batches overlap; they are in stream order anyway, but the UPLOAD of batch b + 1 must not
+        // overwrite what batch b's kernels still read: every batch gets its own slice of the slots
+        const size_t nb = batches.size();
+        PB3D_TRY(pb3d_scratch(ctx, 36, desc_bytes * nb, &dd));
+        PB3D_TRY(pb3d_scratch(ctx, 33, par_bytes * nb, &dp));
+        PB3D_TRY(pb3d_scratch(ctx, 38, tab_bytes, &dt));
+        for (size_t bi = 0; bi < nb; ++bi) {
+            const i64 a = batches[bi].first, e = batches[bi].second;
+            keep_d.emplace_back(); keep_p.emplace_back();
+            std::vector<CropDesc>& ds = keep_d.back();
+            std::vector<RotParams>& ps = keep_p.back();
+            int g0 = 0;
+            u32 cell_off = 0;
+            int maxcells = 0;
+            for (i64 k = a; k < e; ++k) {
+                const i64* b = bbox_lo_hi + 6 * k;
+                CropDesc d;
+                memset(&d, 0, sizeof(d));
+                d.x0 = (int)b[0]; d.y0 = (int)b[1]; d.z0 = (int)b[2];
+                d.Wc = (int)(b[3] - b[0]); d.Hc = (int)(b[4] - b[1]); d.Dc = (int)(b[5] - b[2]);
+                d.id = (int)(k + 1); d.g0 = g0; d.ng = (d.Hc + 31) / 32; d.pitch = d.Dc | 1;
+                d.mask_off = (u32)mask_off[k]; d.cell_off = cell_off;
+                g0 += d.ng;
+                cell_off += (u32)(d.Wc * d.Dc) * (u32)(nrot > 0 ? nrot : 1);
+                maxcells = std::max(maxcells, d.Wc * d.Dc);
+                ds.push_back(d);
+                const i64 shape[3] = {d.Wc, d.Hc, d.Dc};
+                for (int s = 0; s < nrot; ++s) {
+                    double M[9], off[3];
+                    PB3D_TRY(pb3d_rotinv((s + 1) * angle_interval, M));
+                    PB3D_TRY(pb3d_offset(M, shape, off));
+                    ps.push_back(RotParams{M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]});
+                }
+            }
+            CropDesc* ddb = (CropDesc*)((char*)dd + desc_bytes * bi);
+            RotParams* dpb = (RotParams*)((char*)dp + par_bytes * bi);
+            PB3D_HIP(hipMemcpyAsync(ddb, ds.data(), ds.size() * sizeof(CropDesc), hipMemcpyHostToDevice, ctx->stream));
+            const int n = (int)(e - a);
+            if (nrot > 0) {
+                PB3D_HIP(hipMemcpyAsync(dpb, ps.data(), ps.size() * sizeof(RotParams), hipMemcpyHostToDevice, ctx->stream));
+                dim3 gridc((unsigned)std::min((maxcells + 255) / 256, 64), (unsigned)(n * nrot));
+                PB3D_REQUIRE(gridc.y <= 65535u, "pb3d_guided_carve: too many (component, step) pairs in a batch");
+                hipLaunchKernelGGL(k_crop_cells, gridc, dim3(256), 0, ctx->stream, (const CropDesc*)ddb, (const RotParams*)dpb, nrot, (u32*)dt);
+            }
+            hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0);
+            PB3D_CHECK_LAUNCH();
+        }
+        static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");
+        PB3D_HIP(hipMemcpyAsync(carved_counts, d_counts, (size_t)ncomp * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        return PB3D_OK;
+    };
+    rc = run();
+    hipError_t es = hipStreamSynchronize(ctx->stream);          // the counts are the caller's (the printed log); the staging vectors die here
+    if (copy) (void)pb3d_dev_free(ctx, copy);
+    if (rc != PB3D_OK) return rc;
+    PB3D_HIP(es);
+    *took = 1;
+    return PB3D_OK;
+}
+
+}  // extern "C"

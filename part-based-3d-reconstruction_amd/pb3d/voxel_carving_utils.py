@@ -271,66 +271,77 @@ def _check_angle_step(angle):
 
 
 def _lrgc_dev(d_col, shape3, mask2d, target_color, angle):
-    """left_right_guided_carve on a device-resident grid; returns a new DeviceBuffer holding the carved copy."""
+    """left_right_guided_carve on a device-resident grid.  Returns the DeviceBuffer that holds the result: d_col itself when the
+    fused component loop ran (csrc/guided.hip: in place, one launch pair per batch of components), else a new buffer."""
     from . import device as dev
     W, H, D = shape3
     lib, ctx = _lib.load(), _lib.ctx()
     nbytes = W * H * D * 3
-    d_carved = dev.DeviceBuffer(nbytes)
-    _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), nbytes))
     d_lab = dev.DeviceBuffer(W * H * D * 4)
+    d_carved = None
     tmp = []
     try:
         cu8 = _color_u8(target_color)
         num = _label(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else 0
         print(f"[{target_color}] 3D components: {num}")
+        if not num:
+            return d_col
         bbox, _, _ = _component_stats(d_lab, (W, H, D), num)
-        lines = []
-        if num:
-            _check_angle_step(angle)
+        _check_angle_step(angle)
+        # every component's 2-D crop mask goes up in ONE transfer and the "carved voxels" counts come back in one (upstream prints
+        # between the steps; the text is the same, it is emitted after the loop)
+        masks, offs, o = [], [], 0
+        for i in range(1, num + 1):
+            x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
+            m = _lib.truth_u8(_mask_to_wh(mask2d[y0:y1, x0:x1], x1 - x0, y1 - y0))
+            masks.append(np.ascontiguousarray(m).reshape(-1)); offs.append(o); o += (m.size + 15) & ~15
+        packed = np.zeros(max(o, 16), np.uint8)
+        for m, off in zip(masks, offs):
+            packed[off:off + m.size] = m
+        counts = None
+        if angle > 0:
+            bb = np.ascontiguousarray(bbox, np.int64); mo = np.asarray(offs, np.int64); cn = np.zeros(num, np.int64)
+            took = C.c_int(0)
+            _lib.check(lib.pb3d_guided_carve_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), W, H, D, num, bb.ctypes.data_as(_lib.i64p),
+                                                 _lib.p_u8(packed), mo.ctypes.data_as(_lib.i64p), packed.size, int(min(angle, 91)),
+                                                 cn.ctypes.data_as(_lib.i64p), C.byref(took)))
+            if took.value:
+                counts = cn
+        if counts is None:
+            # a crop too large for the LDS-resident chain (or an empty angle loop): component by component, into a copy
+            d_carved = dev.DeviceBuffer(nbytes)
+            _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), nbytes))
             vmax = int(max((b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]) for b in bbox))
-            # every component's 2-D crop mask goes up in ONE transfer and the "carved voxels" counts come back in one: the component
-            # loop then queues kernels only (upstream prints between the steps; the text is the same, it is emitted after the loop)
-            masks, offs, o = [], [], 0
-            for i in range(1, num + 1):
-                x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
-                m = _lib.truth_u8(_mask_to_wh(mask2d[y0:y1, x0:x1], x1 - x0, y1 - y0))
-                masks.append(np.ascontiguousarray(m).reshape(-1)); offs.append(o); o += (m.size + 15) & ~15
-            packed = np.zeros(max(o, 16), np.uint8)
-            for m, off in zip(masks, offs):
-                packed[off:off + m.size] = m
             d_m = dev.from_numpy(packed)
             d_occ = dev.DeviceBuffer(vmax); d_out = dev.DeviceBuffer(vmax); d_tmp = dev.DeviceBuffer(vmax)
             d_cnt = dev.DeviceBuffer(8 * num); d_cnt.zero()
             tmp = [d_occ, d_out, d_tmp, d_m, d_cnt]
+            for i in range(1, num + 1):
+                x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
+                Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
+                lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
+                _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
+                if angle < 0:
+                    src = d_occ     # empty angle loop: the crop's occupancy is returned as is
+                else:
+                    dev.process_grid(d_occ, Wc, Hc, Dc, d_m.at(offs[i - 1]), int(min(angle, 91)), d_out, d_tmp)
+                    src = d_out
+                _lib.check(lib.pb3d_count_nonzero_dev(ctx, C.c_void_p(src.ptr), Wc * Hc * Dc, d_cnt.at(8 * (i - 1))))
+                _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
+                                                        lo, hi, C.c_void_p(d_carved.ptr)))
+            counts = d_cnt.download((num,), np.int64)
+        lines = []
         for i in range(1, num + 1):
             x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
             lines.append(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
-            Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
-            lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
-            _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
-            if angle < 0:
-                src = d_occ     # empty angle loop: the crop's occupancy is returned as is
-            else:
-                dev.process_grid(d_occ, Wc, Hc, Dc, d_m.at(offs[i - 1]), int(min(angle, 91)), d_out, d_tmp)
-                src = d_out
-            _lib.check(lib.pb3d_count_nonzero_dev(ctx, C.c_void_p(src.ptr), Wc * Hc * Dc, d_cnt.at(8 * (i - 1))))
-            lines.append(None)          # the count of component i, filled in below
-            _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
-                                                    lo, hi, C.c_void_p(d_carved.ptr)))
-        if num:
-            counts = d_cnt.download((num,), np.int64)
-            k = 0
-            for n_, ln in enumerate(lines):
-                if ln is None:
-                    lines[n_] = f"    carved voxels: {int(counts[k])}"; k += 1
-            print("\n".join(lines))
+            lines.append(f"    carved voxels: {int(counts[i - 1])}")
+        print("\n".join(lines))
         dev.sync()
-        return d_carved
-    except BaseException:
-        d_carved.free()
-        raise
+        res, d_carved = (d_carved if d_carved is not None else d_col), None
+        return res
     finally:
+        if d_carved is not None:
+            d_carved.free()
         d_lab.free()
         for b in tmp:
             b.free()
@@ -356,7 +367,8 @@ def left_right_guided_carve(colored_grid, semantic_mask, target_color, angle=60,
         try:
             return d_carved.download(g.shape)
         finally:
-            d_carved.free()
+            if d_carved is not d_col:
+                d_carved.free()
     finally:
         d_col.free()
 
@@ -501,9 +513,10 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
                 print(f"[SKIP] No mask for color {target}")
                 continue
             d_b = _lrgc_dev(d_a, (W, H, D), mask2d, target, angle)
-            live.append(d_b)
-            d_a.free(); live.remove(d_a)
-            d_a = d_b
+            if d_b is not d_a:          # (the fused component loop works in place)
+                live.append(d_b)
+                d_a.free(); live.remove(d_a)
+                d_a = d_b
         show(d_a, g.shape, "After part-wise symmetric carving (local symmetry on each part)")
         # 3. interior extrusion: four directions per part, IN PLACE (a column is scanned and painted by one wavefront / thread), the
         #    part's mask uploaded once per axis orientation

@@ -453,6 +453,51 @@ def test_connected_components_row_frame_shapes(pb3d_gpu, oracle):
             d_g.free(); d_lab.free()
 
 
+def test_guided_carve_fused_component_loop(pb3d_gpu, oracle):
+    """N1 as one launch sequence (csrc/guided.hip): every component's 32-plane slices stay in LDS for all rotation steps, the grid is
+    carved in place.  Against the oracle incl. the printed log: interlocking components whose boxes OVERLAP (a later crop sees -- and
+    may restore -- an earlier component's voxels: batches + a copy), more components than one batch holds, tall crops (several plane
+    groups), the angle steps of the notebook (5, 45) and an empty rotation loop (angle > 90)."""
+    import contextlib
+    import io
+    rng = np.random.default_rng(77)
+    col = np.array(pb3d_gpu.PART_COLORS["dome"], np.uint8)
+    other = np.array(pb3d_gpu.PART_COLORS["plinth"], np.uint8)
+    cases = []
+    # (a) two interlocking L shapes + a far blob, boxes overlap
+    W, H, D = 40, 70, 36
+    g = np.zeros((W, H, D, 3), np.uint8)
+    g[2:30, 3:60, 4:8] = col; g[2:6, 3:60, 4:30] = col                       # L one: box x 2..30, z 4..30
+    g[10:28, 5:66, 12:28] = col                                              # block two, inside L one's box, not touching it
+    g[12:20, 20:40, 14:20] = other                                           # foreign colour inside block two
+    g[36:39, 10:20, 30:35] = col
+    g[rng.random((W, H, D)) < 0.03] = 0
+    cases.append((g, W, H, D))
+    # (b) many small components (more than one batch), random boxes that overlap a lot
+    W, H, D = 48, 40, 48
+    g = np.zeros((W, H, D, 3), np.uint8)
+    for _ in range(90):
+        lo = [int(rng.integers(0, s - 2)) for s in (W, H, D)]
+        hi = [min(s, l + int(rng.integers(1, 7))) for s, l in zip((W, H, D), lo)]
+        g[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = col if rng.random() < 0.8 else other
+    cases.append((g, W, H, D))
+    # (c) one solid component, odd sizes
+    W, H, D = 33, 45, 31
+    g = np.zeros((W, H, D, 3), np.uint8); g[3:30, 2:44, 1:29] = col; g[rng.random((W, H, D)) < 0.1] = other
+    cases.append((g, W, H, D))
+    for (g, W, H, D) in cases:
+        sem = np.zeros((H, W, 3), np.uint8)
+        sem[rng.random((H, W)) < 0.85] = col
+        for angle in (5, 45, 60, 120):
+            b1, b2 = io.StringIO(), io.StringIO()
+            with contextlib.redirect_stdout(b1):
+                got = pb3d_gpu.left_right_guided_carve(g, sem, col, angle=angle)
+            with contextlib.redirect_stdout(b2):
+                want = oracle.left_right_guided_carve(g, sem, col, angle=angle)
+            assert np.array_equal(got, want), (W, H, D, angle, int((got != want).any(-1).sum()))
+            assert b1.getvalue() == b2.getvalue(), (W, H, D, angle)
+
+
 @pytest.mark.parametrize("name", ["Taj_96", "Akbar_64", "Bibi_80"])
 def test_partwise_stages_f5(pb3d_gpu, golden, name):
     """N1/N2: component-guided carve (incl. its printed log), extrusion, recolouring and the whole partwise_carve
