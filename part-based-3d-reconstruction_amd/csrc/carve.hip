@@ -660,13 +660,18 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         }
     }
     job_skip = skip_rest.data();
+    const bool wide = D >= 16 && nvox < (1ll << 32) && aligned16(d_colored) && aligned16(d_out);   // scratch buffers are 4 KiB aligned
+    int nrest_all = 0;
+    for (int j = 0; j < njobs; ++j) nrest_all += job_skip[j] ? 0 : 1;
+    const bool multi = wide && nrest_all >= 1 && nrest_all <= 8 && nvox % 16 == 0 && ctx->tune_misc[3] != 2;
+    // every slot is requested ONCE with the size its path needs: a regrow frees and reallocates (and drops the cached rotation tables,
+    // among them the set the first job's prefetch is about to build)
     void *occ, *carved, *tmp, *keep;
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &occ));
-    PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));
+    PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox * (size_t)(multi ? nrest_all : 1), &carved));
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nvox, &tmp));
-    PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)nvox, &keep));
+    PB3D_TRY(pb3d_scratch(ctx, 7, std::max((size_t)nvox, (size_t)(W * H) * sizeof(u32)), &keep));
     const unsigned blocks = pb3d_stream_blocks(ctx, nvox, 256, 8);
-    const bool wide = D >= 16 && nvox < (1ll << 32) && aligned16(d_colored) && aligned16(d_out);   // scratch buffers are 4 KiB aligned
     const i64 ngroups = nvox / 16, vtail = 16 * ngroups;                    // the last nvox % 16 voxels: scalar kernels from vtail on
     const pb3d_magic mD = pb3d_make_magic((u32)(D > 0 ? D : 1));
     const unsigned gblocks = pb3d_stream_blocks(ctx, ngroups > 0 ? ngroups : 1, 256, 8);
@@ -676,10 +681,8 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
     int nrest = 0;
     for (int j = 0; j < njobs; ++j)
         if (!job_skip[j]) { if (jl.n < 8) jl.j[jl.n++] = j; ++nrest; }
-    if (wide && nrest >= 1 && nrest <= 8 && nvox % 16 == 0 && ctx->tune_misc[3] != 2) {
-        void *carvedN, *S;
-        PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox * (size_t)nrest, &carvedN));
-        PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H) * sizeof(u32), &S));
+    if (multi) {
+        void *carvedN = carved, *S = keep;
         for (int k = 0; k < jl.n; ++k) {
             const int j = jl.j[k];
             const u8* ms = d_mask_sub + (i64)j * W * H;

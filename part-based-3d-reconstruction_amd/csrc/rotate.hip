@@ -1430,7 +1430,7 @@ static bool table_step_takes_src_mask(i64 W, i64 H, i64 D) { return H >= 32 && W
 
 // ---- the two table sets ------------------------------------------------------------------------------------------------------
 struct TableSet { void *cells, *lutmap, *parts, *tinfo, *runs; };
-static const int kSetSlots[2][5] = {{16, 20, 17, 18, 19}, {26, 27, 28, 29, 30}};
+static const int kSetSlots[2][5] = {{16, 31, 17, 18, 19}, {26, 27, 28, 29, 30}};   // (no slot the auxiliary stream writes is shared with main-stream-only code)
 
 // which tile kernel a table-driven step uses: 1 packed 256-tiles, 2 wide 128-tiles, 3 64-tiles (the parity tests pin each of them on
 // the same grids: ctx->tune_rotate_tile = 64 / 128 / 256)
@@ -1660,6 +1660,10 @@ int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9]
     if (d_rgb_hw3) hipLaunchKernelGGL(k_first_step<true>, grid, dim3(256), (size_t)W * 4, ctx->stream, (const CellRec*)cells, (const u32*)pbits, d_rgb_hw3, W, H, D, d_out);
     else hipLaunchKernelGGL(k_first_step<false>, grid, dim3(256), (size_t)W * 4, ctx->stream, (const CellRec*)cells, (const u32*)pbits, d_rgb_hw3, W, H, D, d_out);
     PB3D_CHECK_LAUNCH();
+    // these kernels read slots 16 / 17 on the main stream: a later prefetch on the auxiliary stream must see them as the set's last
+    // readers and must not pick set 0 as the "older" one while they run
+    PB3D_TRY(mark_used(ctx, 0));
+    ctx->rot_cache[0].stamp = ++ctx->rot_stamp;
     return PB3D_OK;
 }
 

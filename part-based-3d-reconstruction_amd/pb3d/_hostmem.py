@@ -20,7 +20,7 @@ import weakref
 
 import numpy as np
 
-_lock = threading.Lock()
+_lock = threading.RLock()      # re-entrant: a finalizer (_give_back) may run on this thread inside empty() when the GC fires there
 _cap_bytes = 0
 _free = []          # released backing buffers (np.uint8 arrays), most recently released last
 _leased_bytes = 0   # bytes of backing buffers currently lent to live results

@@ -199,21 +199,23 @@ class ControlPlane:
                 return None
             _send_frame(c, {"t": "ok", "v": hmac.new(secret, bytes.fromhex(want), hashlib.sha256).hexdigest()})
             return msg["r"]
-        except (OSError, ValueError, ControlPlaneError):
+        except (OSError, ValueError, TypeError, AttributeError, ControlPlaneError):
             return None
 
     def _handshake_client(self, c, secret):
         try:
             c.settimeout(5.0)
             msg = _recv_frame(c)
-            if msg.get("t") != "hello":
+            if msg.get("t") != "hello" or not isinstance(msg.get("v"), str):
                 return False
             nonce = bytes.fromhex(msg["v"])
             mine = hmac.new(secret, nonce + struct.pack("!I", self.rank), hashlib.sha256).hexdigest()
             _send_frame(c, {"t": "auth", "r": self.rank, "v": mine})
             ok = _recv_frame(c)
-            return ok.get("t") == "ok" and hmac.compare_digest(ok.get("v", ""), hmac.new(secret, bytes.fromhex(mine), hashlib.sha256).hexdigest())
-        except (OSError, ValueError, ControlPlaneError):
+            if ok.get("t") != "ok" or not isinstance(ok.get("v"), str):
+                return False
+            return hmac.compare_digest(ok["v"], hmac.new(secret, bytes.fromhex(mine), hashlib.sha256).hexdigest())
+        except (OSError, ValueError, TypeError, AttributeError, ControlPlaneError):
             return False
 
     # ---- typed, sequence-numbered frames ---------------------------------------------------------------------------------
