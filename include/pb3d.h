@@ -243,6 +243,12 @@ int pb3d_scatter_colors_dev(pb3d_ctx* ctx, const int64_t* d_coords, const uint8_
  * valid[y*valid_w + z], the upstream indexing of its (H,W) mask). */
 int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
                          int32_t* d_labels, int64_t* ncomp);
+/* label_color + component_stats in one pass and ONE host round trip: the statistics are gathered by the labelling's last kernel
+ * (the labels are in registers there).  The host arrays hold `cap` components; *stats_valid = 0 when there are more (only *ncomp and
+ * the labels are then valid: call pb3d_component_stats_dev). */
+int pb3d_label_color_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
+                               int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum,
+                               int* stats_valid);
 int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0, int64_t A1, int64_t A2, int64_t ncomp,
                              int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum);
 int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],

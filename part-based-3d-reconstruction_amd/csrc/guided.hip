@@ -73,12 +73,25 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
     const int dx = GTHREADS / Dc, dz = GTHREADS - dx * Dc;
     const int xs0 = tid / Dc, zs0 = tid - xs0 * Dc;
     const i64 rowb = D * 3;                              // bytes from plane y to plane y + 1 of the grid
+    // Every loop below is latency-bound if written cell by cell (a dependent global load per iteration: the first version spent
+    // 220 us on a dome crop): loads are issued eight at a time before any of them is used.
     {   // occupancy of the crop (any channel > 0, reference :190), 32 planes per cell, with the 0-degree carve (:124, first iteration)
         int xs = xs0, zs = zs0;
         for (int cell = tid; cell < ncell; cell += GTHREADS) {
             const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * 3;
             u32 bits = 0;
-            for (int q = 0; q < np; ++q) { const u8* v = p + (i64)q * rowb; bits |= (u32)((v[0] | v[1] | v[2]) != 0) << q; }
+            for (int q0 = 0; q0 < np; q0 += 8) {
+                u32 any[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = q0 + k < np ? q0 + k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
+                    const u8* v = p + (i64)q * rowb;
+                    any[k] = (u32)v[0] | (u32)v[1] | (u32)v[2];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (q0 + k < np) bits |= (u32)(any[k] != 0) << (q0 + k);
+            }
             A[xs * pitch + zs] = bits & mb[xs];
             xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
         }
@@ -87,11 +100,17 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
     for (int s = 0; s < nrot; ++s) {
         const u32* ct = celltab + (i64)d.cell_off + (i64)s * ncell;
         int xs = xs0, zs = zs0;
-        for (int cell = tid; cell < ncell; cell += GTHREADS) {
-            const u32 w = ct[cell];
-            const u32* tp = A + (w & 0xffffu);
-            B[xs * pitch + zs] = lut_apply32(w >> 16, tp[0], tp[1], tp[pitch], tp[pitch + 1]) & mb[xs];
-            xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
+        for (int base = tid; base < ncell; base += 8 * GTHREADS) {
+            u32 w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int cell = base + k * GTHREADS; w[k] = cell < ncell ? ct[cell] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (base + k * GTHREADS >= ncell) break;
+                const u32* tp = A + (w[k] & 0xffffu);
+                B[xs * pitch + zs] = lut_apply32(w[k] >> 16, tp[0], tp[1], tp[pitch], tp[pitch + 1]) & mb[xs];
+                xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
+            }
         }
         __syncthreads();
         u32* t2 = A; A = B; B = t2;
@@ -105,9 +124,15 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
             const u32 R = A[xs * pitch + zs];
             cnt += (unsigned long long)__popc(R);
             const i64 v0 = ((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs;
-            for (u32 todo = ~R & live; todo; todo &= todo - 1) {
-                const i64 v = v0 + (i64)__builtin_ctz(todo) * D;
-                if (labels[v] == d.id) { u8* o = dst_rgb + 3 * v; o[0] = 0; o[1] = 0; o[2] = 0; }
+            const u32 todo = ~R & live;
+            for (int q0 = 0; q0 < np; q0 += 8) {
+                if (!((todo >> q0) & 0xffu)) continue;
+                int lab[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) lab[k] = ((todo >> (q0 + k)) & 1u) ? labels[v0 + (i64)(q0 + k) * D] : 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (lab[k] == d.id) { u8* o = dst_rgb + 3 * (v0 + (i64)(q0 + k) * D); o[0] = 0; o[1] = 0; o[2] = 0; }
             }
             if (restore) {          // boxes overlap somewhere: an EARLIER component may have cleared a voxel this crop keeps -- write it back (:200-201)
                 for (u32 kept = R & live; kept; kept &= kept - 1) {

@@ -117,14 +117,50 @@ def apply_colored_mask_to_voxel_grid(carved_voxel_grid, colored_mask):
     return out
 
 
+# Derived 2-D masks are memoised by CONTENT (xxhash of the image bytes, ~40 us for a 278 x 512 x 3 mask): notebook 1 passes the same
+# semantic masks to global_carve, part_carve, partwise_carve and every left_right_guided_carve, and the NumPy work on them (colour
+# keys, per-job selections, transposes: ~4 ms per partwise_carve at Taj 512) was half the wall time of the resident chain.  Without
+# the xxhash module nothing is memoised.
+try:
+    import xxhash as _xx
+except Exception:       # pragma: no cover - optional accelerator
+    _xx = None
+_memo = {}
+
+
+def _digest(a):
+    if _xx is None or not isinstance(a, np.ndarray) or a.dtype == object or not a.flags["C_CONTIGUOUS"]:
+        return None
+    return (_xx.xxh3_128_digest(a), a.shape, a.dtype.str)
+
+
+def _memo_get(kind, dig, extra=()):
+    return None if dig is None else _memo.get((kind, dig, extra))
+
+
+def _memo_put(kind, dig, extra, value):
+    if dig is not None:
+        if len(_memo) >= 64:
+            _memo.pop(next(iter(_memo)))
+        _memo[(kind, dig, extra)] = value
+    return value
+
+
 def _color_key(img_hw3):
     """(H,W) uint32 image r | g << 8 | b << 16 of an (H,W,3) uint8 image: one pass, then every np.all(img == colour, axis=-1)
     is a single integer compare (the per-colour broadcast compare of a 278 x 512 mask costs ~4 ms in NumPy, this ~0.05 ms)."""
     a = np.asarray(img_hw3)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
         return None
-    a = a.astype(np.uint32)
-    return a[..., 0] | (a[..., 1] << 8) | (a[..., 2] << 16)
+    dig = _digest(a)
+    hit = _memo_get("key", dig)
+    if hit is not None:
+        return hit
+    a4 = np.zeros(a.shape[:2] + (4,), np.uint8)
+    a4[..., :3] = a
+    key = a4.view("<u4")[..., 0]
+    key.flags.writeable = False
+    return _memo_put("key", dig, (), key)
 
 
 def _is_color(img_hw3, key, color):
@@ -138,6 +174,17 @@ def _is_color(img_hw3, key, color):
 def _job_masks(semantic_mask, group_jobs, W, H, part_colors):
     """Per job: (mask2d.T as uint8, what _mask_to_wh makes of it, angle, skip) -- reference :143-151."""
     sm = np.asarray(semantic_mask)
+    dig = _digest(sm)
+    try:
+        extra = (W, H, tuple((tuple(names), int(angle)) for names, angle in group_jobs),
+                 tuple(tuple(int(v) for v in np.asarray(part_colors[n]).reshape(-1)) for names, _ in group_jobs for n in names))
+    except Exception:
+        dig, extra = None, ()
+    hit = _memo_get("jobs", dig, extra)
+    if hit is not None:
+        msub, mcarve, ang, sk = hit
+        nj1 = len(ang)
+        return msub, mcarve, (C.c_int * nj1)(*ang), (C.c_int * nj1)(*sk)       # (the ctypes arrays are the caller's to modify)
     key = _color_key(sm)
     nj = len(group_jobs)
     msub = np.zeros((max(nj, 1), W, H), np.uint8)
@@ -155,6 +202,8 @@ def _job_masks(semantic_mask, group_jobs, W, H, part_colors):
             raise ValueError(f"operands could not be broadcast together: mask {m.shape} vs grid ({W},{H})")
         msub[j] = m
         mcarve[j] = _mask_to_wh(m, W, H)
+    msub.flags.writeable = False; mcarve.flags.writeable = False
+    _memo_put("jobs", dig, extra, (msub, mcarve, tuple(angles), tuple(skip)))
     return msub, mcarve, angles, skip
 
 
@@ -263,6 +312,20 @@ def _component_stats(d_labels, shape3, n):
     return bbox[:n], cnt[:n], sums[:n]
 
 
+def _label_stats(d_grid, shape3, color_u8, d_labels, cap=1024):
+    """_label + _component_stats in one device pass and one host round trip (pb3d_label_color_stats_dev); scenes with more than
+    `cap` components take the separate statistics pass."""
+    A0, A1, A2 = shape3
+    n = C.c_int64(0); ok = C.c_int(0)
+    bbox = np.zeros((cap, 6), np.int64); cnt = np.zeros(cap, np.int64); sums = np.zeros((cap, 3), np.int64)
+    _lib.check(_lib.load().pb3d_label_color_stats_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, _lib.p_u8(color_u8), C.c_void_p(d_labels.ptr),
+                                                      C.byref(n), cap, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
+                                                      sums.ctypes.data_as(_lib.i64p), C.byref(ok)))
+    if not ok.value:
+        return (n.value,) + _component_stats(d_labels, shape3, n.value)
+    return n.value, bbox[:n.value], cnt[:n.value], sums[:n.value]
+
+
 def _check_angle_step(angle):
     if isinstance(angle, (bool, np.bool_)) or not isinstance(angle, (int, np.integer)):
         raise TypeError(f"'{type(angle).__name__}' object cannot be interpreted as an integer")
@@ -282,11 +345,10 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle):
     tmp = []
     try:
         cu8 = _color_u8(target_color)
-        num = _label(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else 0
+        num, bbox, _, _ = _label_stats(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else (0, None, None, None)
         print(f"[{target_color}] 3D components: {num}")
         if not num:
             return d_col
-        bbox, _, _ = _component_stats(d_lab, (W, H, D), num)
         _check_angle_step(angle)
         # every component's 2-D crop mask goes up in ONE transfer and the "carved voxels" counts come back in one (upstream prints
         # between the steps; the text is the same, it is emitted after the loop)
@@ -433,10 +495,9 @@ def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis):
         return
     d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
     try:
-        n = _label(d_g, (A0, A1, A2), cu8, d_lab)
+        n, _, cnt, sums = _label_stats(d_g, (A0, A1, A2), cu8, d_lab)
         if n == 0:
             return
-        _, cnt, sums = _component_stats(d_lab, (A0, A1, A2), n)
         means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column
         keep = {i for i, _ in sorted(means, key=lambda t: t[1])[:k]}
         flags = np.array([0 if (i + 1) in keep else 1 for i in range(n)], np.uint8)

@@ -450,6 +450,15 @@ def test_connected_components_row_frame_shapes(pb3d_gpu, oracle):
             if n:
                 bbox, cnt, sums = _component_stats(d_lab, shp, n)
                 assert np.array_equal(cnt, np.bincount(want.ravel(), minlength=n + 1)[1:]), (shp, dens)
+                # the statistics gathered by the labelling's own last pass (one round trip) == the separate pass; a capacity below the
+                # component count falls back to it
+                from pb3d.voxel_carving_utils import _label_stats
+                for cap in (4096, 70, 2):
+                    d_l2 = dev.DeviceBuffer(mask.size * 4)
+                    n2, b2, c2, s2 = _label_stats(d_g, shp, col, d_l2, cap=cap)
+                    assert n2 == n and np.array_equal(d_l2.download(shp, np.int32), want), (shp, dens, cap)
+                    assert np.array_equal(b2, bbox) and np.array_equal(c2, cnt) and np.array_equal(s2, sums), (shp, dens, cap)
+                    d_l2.free()
             d_g.free(); d_lab.free()
 
 
