@@ -143,8 +143,10 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
                           const uint8_t* colors, int ncolors, int stride, int64_t* n);
 int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C,
                          const uint8_t* colors, int ncolors, int stride, int64_t n, float* d_pts, uint8_t* d_cols);
-/* One-pass form for resident callers (stride 1): the selected voxels are counted AND written in a single sweep of the grid (ordered
- * stream compaction with a decoupled look-back; the count -> allocate -> fill protocol of the NumPy surface reads the grid twice).
+/* One-pass form (stride 1) FOR CAPACITY-BOUNDED CALLERS ONLY -- it is the SLOWER form on MI355X: count + fill above takes 2.3 ms at
+ * 1024^3 / 416 M points, this entry 4.1-4.5 ms (a decoupled look-back waits for flags that cross XCDs).  Use
+ * it when the output buffers exist before the count is known and a second sweep cannot be scheduled; otherwise count, then fill.
+ * The selected voxels are counted AND written in a single sweep of the grid (ordered stream compaction).
  * capacity = rows d_pts (n x 3 float32) / d_cols (n x C) can take; *n is the number of selected voxels.  If *n > capacity the
  * buffers hold only whole blocks that fitted and the call must be repeated with capacity >= *n.  Synchronises (returns *n). */
 int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, int C, const uint8_t* colors, int ncolors,

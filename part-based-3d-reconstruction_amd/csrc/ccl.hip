@@ -421,7 +421,8 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     PB3D_CHECK_LAUNCH();
     if (stats) {
         hipLaunchKernelGGL(k_fin_stats_init, dim3((unsigned)((dcap + 255) / 256)), dim3(256), 0, ctx->stream, dcap, (int*)sbb, (unsigned long long*)scs);
-        hipLaunchKernelGGL(k_ccl_finish<true>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
+        // (a capped grid: every block ends with a flush of its table -- global atomics on the few component records)
+        hipLaunchKernelGGL(k_ccl_finish<true>, dim3(pb3d_stream_blocks(ctx, rows, 4, 8)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
                            parent, m1, dcap, (int*)sbb, (unsigned long long*)scs);
     } else {
         hipLaunchKernelGGL(k_ccl_finish<false>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,

@@ -52,6 +52,11 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));
     PB3D_TRY(pb3d_transpose_mask_dev(ctx, d_bin_hw, H, W, (u8*)mwh));
     const i64 shape[3] = {W, H, D};
+    if (nsteps >= 3 && ctx->tune_misc[3] != 1) {                    // two and more rotation steps: bit-sliced from the mask to the colours
+        int took = 0;
+        PB3D_TRY(pb3d_global_carve_sliced(ctx, (const u8*)mwh, d_rgb_hw3, W, H, D, angle_interval, d_out_slab, &took));
+        if (took) return PB3D_OK;
+    }
     if (nsteps >= 2 && ctx->tune_misc[3] != 1) {                    // tune misc3 = 1: the composed pipeline (parity tests run both)
         double M1[9], off1[3];
         PB3D_TRY(pb3d_rotinv(angle_interval, M1));

@@ -163,6 +163,8 @@ __device__ __forceinline__ u32 pb3d_div(u32 n, const pb3d_magic g) {
 // process_voxel_grid through the bit-sliced chain (csrc/sliced.hip); *took = 0: not applicable, nothing written
 int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
                              int known_binary, int* took);
+int pb3d_global_carve_sliced(pb3d_ctx* ctx, const u8* d_mask_wh, const u8* d_rgb_hw3, i64 W, i64 H, i64 D, int angle_interval, u8* d_out_rgb,
+                             int* took);
 // pb3d_process_grid_dev for callers whose grid is 0/1 by construction (occupancy of a colour grid, all-ones): no host wait
 int pb3d_process_grid_binary_dev(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
                                  u8* d_tmp);

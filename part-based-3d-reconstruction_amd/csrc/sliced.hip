@@ -126,6 +126,63 @@ __global__ __launch_bounds__(256) void k_s32_unslice(const u32* __restrict__ in,
     }
 }
 
+// the all-ones grid of global_carve (reference :279) after its 0-degree carve: every voxel of column (x, y) is mask[x, y], so the
+// sliced volume is the row's mask word repeated along z (pad columns zero) -- written, never sliced from bytes
+__global__ __launch_bounds__(256) void k_s32_fill(u32* __restrict__ out, const u32* __restrict__ mbits, i64 D, i64 Dp, pb3d_magic mzq, u32 total) {
+    const u32 idx = blockIdx.x * 256u + threadIdx.x;                 // one thread = 4 dwords
+    if (idx >= total) return;
+    const u32 row = pb3d_div(idx, mzq), zq = idx - row * mzq.d;
+    const u32 m = mbits[row];
+    const i64 z = 4 * (i64)zq;
+    u32x4 v;
+    v.x = z < D ? m : 0u; v.y = z + 1 < D ? m : 0u; v.z = z + 2 < D ? m : 0u; v.w = z + 3 < D ? m : 0u;
+    *(u32x4*)(out + (i64)row * Dp + z) = v;
+}
+
+// 4 occupancy bytes (0/1) -> the 12 colour bytes of 4 voxels (C0 = R|G<<8|B<<16|R<<24, C1 = G|B<<8|R<<16|G<<24, C2 = B|R<<8|G<<16|B<<24)
+__device__ __forceinline__ void rgb4(u32 occ01, u32 C0, u32 C1, u32 C2, u32* o) {
+    const u32 e = occ01 * 0xffu;                                                              // bytes 0x00 / 0xff (no carries)
+    o[0] = pperm(e, e, 0x01000000u) & C0; o[1] = pperm(e, e, 0x02020101u) & C1; o[2] = pperm(e, e, 0x03030302u) & C2;
+}
+
+// S32 -> (W,H,D,3) colours: apply_colored_mask_to_voxel_grid (reference :128-136) folded into the un-slicing -- voxel (x,y,z) gets
+// rgb_hw3[y, x] where its bit is set.  Same thread shape as k_s32_unslice; a thread writes 24 contiguous bytes per plane, a wave 1.5 KB.
+__global__ __launch_bounds__(256) void k_s32_unslice_rgb(const u32* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ rgb_hw3, i64 W, i64 H,
+                                                         i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total) {
+    const u32 idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total) return;
+    const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
+    const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
+    const i64 z = 8 * (i64)zb;
+    const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
+    const u32* ip = in + (i64)row * Dp + z;
+    const u32x4 a = *(const u32x4*)ip, b = *(const u32x4*)(ip + 4);
+    u32 vl[4], vh[4];
+    tr4x4(a.x, a.y, a.z, a.w, vl);
+    tr4x4(b.x, b.y, b.z, b.w, vh);
+    u8* base = out + (((i64)x * H + 32 * (i64)g) * D + z) * 3;
+    const u8* px = rgb_hw3 + ((32 * (i64)g) * W + x) * 3;
+    const bool whole = z + 8 <= D;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q >= np) break;
+        const u8* c = px + (i64)q * W * 3;
+        const u32 R = c[0], G = c[1], B = c[2];
+        const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
+        u32 o[6];
+        rgb4((vl[q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o);
+        rgb4((vh[q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o + 3);
+        u8* dp = base + (i64)q * D * 3;
+        if (whole) {
+            u32x2 v0, v1, v2;
+            v0.x = o[0]; v0.y = o[1]; v1.x = o[2]; v1.y = o[3]; v2.x = o[4]; v2.y = o[5];
+            *(u32x2_a1*)dp = v0; *(u32x2_a1*)(dp + 8) = v1; *(u32x2_a1*)(dp + 16) = v2;
+        } else {
+            for (int bb = 0; bb < 24 && z * 3 + bb < D * 3; ++bb) dp[bb] = (u8)(o[bb >> 2] >> (8 * (bb & 3)));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // Tile programs.  One workgroup per (step, tile): every thread evaluates SciPy's coordinates, weights and result table of its 16
 // cells ONCE (f64, no contraction), the workgroup finds the bounding rows / per-row column extents of the taps (a rotated tile is
@@ -304,8 +361,10 @@ static bool step_fits(const double M[9]) {
 // process_voxel_grid(occ, mask, angle_interval) (reference utils/voxel_carving_utils.py:104-126) through the bit-sliced chain.
 // *took = 0: the chain does not apply (fewer than two rotation steps, shape limits, tuning, or -- unless known_binary -- data that
 // is not 0/1): nothing was written and the caller runs the byte chain.  known_binary = 0 costs one host wait for the slice kernel.
-int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
-                             int known_binary, int* took) {
+// d_occ == NULL: the source is the all-ones grid of global_carve (nothing is read).  d_rgb_hw3 != NULL: d_out is the (W,H,D,3)
+// colour volume of global_carve (reference :289), written by the un-slicing pass.
+static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out, const u8* d_rgb_hw3,
+                     int known_binary, int* took) {
     *took = 0;
     const int nsteps = 90 / angle_interval + 1;
     const int nrot = nsteps - 1;
@@ -331,8 +390,13 @@ int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D
         hipLaunchKernelGGL(k_s32_maskbits, dim3((unsigned)(((i64)G * W + 255) / 256)), dim3(256), 0, ctx->stream, d_mask_wh, W, H, G, (u32*)mb, flag);
         const u32 total = (u32)((i64)G * W * nzb);
         const pb3d_magic mzb = pb3d_make_magic((u32)nzb), mw = pb3d_make_magic((u32)W);
-        hipLaunchKernelGGL(k_s32_slice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, (const u32*)mb, W, H, D, Dp, mzb, mw,
-                           total, flag);
+        if (d_occ) {
+            hipLaunchKernelGGL(k_s32_slice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, (const u32*)mb, W, H, D, Dp, mzb, mw,
+                               total, flag);
+        } else {
+            const u32 tq = (u32)((i64)G * W * (Dp / 4));
+            hipLaunchKernelGGL(k_s32_fill, dim3((tq + 255u) / 256u), dim3(256), 0, ctx->stream, (u32*)A, (const u32*)mb, D, Dp, pb3d_make_magic((u32)(Dp / 4)), tq);
+        }
         PB3D_CHECK_LAUNCH();
         int* hflag = (int*)((char*)ctx->pinned + ctx->pinned_bytes - 64);
         if (!known_binary) {
@@ -383,7 +447,11 @@ int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D
             }
             PB3D_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL(k_s32_unslice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, W, H, D, Dp, mzb, mw, total);
+        if (d_rgb_hw3)
+            hipLaunchKernelGGL(k_s32_unslice_rgb, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, d_rgb_hw3, W, H, D, Dp, mzb, mw,
+                               total);
+        else
+            hipLaunchKernelGGL(k_s32_unslice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, W, H, D, Dp, mzb, mw, total);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     };
@@ -393,4 +461,16 @@ int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D
     if (rc == PB3D_EUNSUPPORTED) return PB3D_OK;          // not 0/1 data: *took stays 0
     if (rc == PB3D_OK) *took = 1;
     return rc;
+}
+
+int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
+                             int known_binary, int* took) {
+    return s32_chain(ctx, d_occ, W, H, D, d_mask_wh, angle_interval, d_out, nullptr, known_binary, took);
+}
+
+// global_carve(binary, rgb, angle_interval) (reference utils/voxel_carving_utils.py:269-298) for chains of two and more rotation
+// steps: mask bits -> S32 -> steps -> colours; the volume exists as bytes only in its final (W,H,D,3) form.
+int pb3d_global_carve_sliced(pb3d_ctx* ctx, const u8* d_mask_wh, const u8* d_rgb_hw3, i64 W, i64 H, i64 D, int angle_interval, u8* d_out_rgb,
+                             int* took) {
+    return s32_chain(ctx, nullptr, W, H, D, d_mask_wh, angle_interval, d_out_rgb, d_rgb_hw3, 1, took);
 }

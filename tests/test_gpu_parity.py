@@ -1325,15 +1325,17 @@ def test_global_carve_fused_chain_other_angles(pb3d_gpu, oracle, golden):
         lab = rng.integers(0, len(pal), (h // 4 + 1, w // 4 + 1)).repeat(4, 0).repeat(4, 1)[:h, :w]
         sem = pal[lab]
         binary = (rng.random((h, w)) < 0.85) & (lab != len(pal) - 1)
-        for ai in (45, 60, 30, 50, 89):
+        for ai in (45, 60, 30, 50, 89, 10):
             want = oracle.global_carve(binary, sem, ai)
-            for composed in (0, 1):
-                pb3d_gpu._lib.set_tuning("misc3", composed)
+            # (composed, sliced): the bit-sliced chain from the mask to the colours (default from two rotation steps up), the byte
+            # chain with the fused first / last steps (tune sliced = 1), the composed pipeline with and without the sliced middle
+            for composed, sliced in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                pb3d_gpu._lib.set_tuning("misc3", composed); pb3d_gpu._lib.set_tuning("sliced", sliced)
                 try:
                     got = pb3d_gpu.global_carve(binary, sem, ai)
                 finally:
-                    pb3d_gpu._lib.set_tuning("misc3", 0)
-                assert np.array_equal(got, want), (h, w, ai, composed, int((got != want).sum()))
+                    pb3d_gpu._lib.set_tuning("misc3", 0); pb3d_gpu._lib.set_tuning("sliced", 0)
+                assert np.array_equal(got, want), (h, w, ai, composed, sliced, int((got != want).sum()))
     for name in ("f4_Akbar_64", "f4_Bibi_64", "f4_Taj_96"):
         g = golden(name)
         assert np.array_equal(pb3d_gpu.global_carve(g["binary"], g["ext"], 45), g["global_carve_45"]), name

@@ -1,5 +1,8 @@
-"""Device-resident timing of every op of the path (M1..M8 of SURVEY.md 8(d)) on synthetic 1024^3 inputs.
-Development/measurement tool: python tools/opbench.py [--size 1024] [--ops M1,M3,...]; one JSON line per op."""
+"""Device-resident timing of every op of the path (M1..M8 of SURVEY.md 8(d), plus the N1/N2 kernels of the notebook-1 chain) on
+synthetic inputs.  Development/measurement tool: python tools/opbench.py [--size 1024] [--shape WxHxD] [--ops M1,M3,...,N2]; one JSON
+line per op.  Pricing: `alg_B_per_voxel` is SURVEY 8(d)'s algorithmic figure for the sweeps that are EXECUTED (a folded 0-degree step
+moves nothing and is not priced); ops whose intermediates are not bytes (the bit-sliced chains) also carry `moved_B_per_voxel`, the
+bytes that cross the HBM by design, and their `frac_of_8TBs` is computed from THAT (never from bytes that are not moved)."""
 import argparse
 import json
 import os
@@ -34,7 +37,7 @@ def timeit(fn, reps, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--ops", default="M1,M2,M3,M4,M5,M6,M7,M8")
+    ap.add_argument("--ops", default="M1,M2,M3,M4,M5,M6,M7,M8,A2,A6,A9,N2")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--tune", default="", help="development knobs, e.g. misc1=6 (pb3d_set_tuning)")
     a = ap.parse_args()
@@ -78,8 +81,15 @@ def main():
     if "M3" in ops:
         report("M3", "process_voxel_grid(occ,binary,90)", timeit(lambda: dev.process_grid(d_occ, S, S, S, d_mwh, 90, d_o1, d_tmp), a.reps), 2)
     if "M3" in ops:
-        for ai in (45, 60, 30):     # chained: len(range(0, 91, ai)) steps, the 0-degree carve folded into the first rotation
-            report("M3+", f"process_voxel_grid(occ,binary,{ai}): {90 // ai + 1} steps", timeit(lambda: dev.process_grid(d_occ, S, S, S, d_mwh, ai, d_o1, d_tmp), a.reps), 2 * (90 // ai + 1))
+        for ai in (45, 60, 30, 5):     # chained: len(range(0, 91, ai)) steps; the 0-degree carve is folded (it moves nothing): 90 // ai sweeps
+            nrot = 90 // ai
+            ms = timeit(lambda: dev.process_grid(d_occ, S, S, S, d_mwh, ai, d_o1, d_tmp), a.reps)
+            # two and more rotation steps run bit-sliced (csrc/sliced.hip): 1 B in, 1/8 out; nrot x (1/8 + 1/8); 1/8 in, 1 B out
+            moved = 2.0 * nrot if nrot < 2 else 2.25 + 0.25 * nrot
+            r = {"op": "M3+", "name": f"process_voxel_grid(occ,binary,{ai}): {nrot} rotation sweeps (0 deg folded)", "size": S, "ms": round(ms, 4),
+                 "ms_per_sweep": round(ms / nrot, 4), "alg_B_per_voxel": 2 * nrot, "alg_GB_s": round(2 * nrot * nvox / ms / 1e6, 1),
+                 "moved_B_per_voxel": moved, "moved_GB_s": round(moved * nvox / ms / 1e6, 1), "frac_of_8TBs": round(moved * nvox / ms / 1e6 / PEAK, 4)}
+            print(json.dumps(r), flush=True)
     if "M4" in ops:
         M = np.empty(9); off = np.empty(3)
         for ang in (45, 5):
@@ -87,7 +97,7 @@ def main():
             report("M4", f"one rotate+carve step, {ang} deg", timeit(lambda: dev.rotate_carve(d_occ, S, S, S, M, off, d_mwh, d_o1), a.reps), 2)
     d_occ.free(); d_o1.free(); d_tmp.free()
     d_col = None
-    if any(o in ops for o in ("M5", "M6", "M7", "M8", "A9")):
+    if any(o in ops for o in ("M5", "M6", "M7", "M8", "A9", "N2")):
         d_col = dev.DeviceBuffer(nvox * 3)
         ms = timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col), a.reps)
         if "M5" in ops:
@@ -112,7 +122,9 @@ def main():
         # the six jobs run as ONE fused sweep (k_part90): it owes a read of the colour grid as occupancy source (3 B), a read of
         # the kept rows as output source (<= 3 B) and the write (3 B) -- <= 9 B/voxel whatever the number of jobs.  (SURVEY's
         # 6 B/voxel PER JOB prices the reference's job-by-job execution, which this sweep does not perform.)
-        report("M6", "part_carve, six 90-degree jobs (one fused sweep)", ms, 9, {"jobs": 6, "ms_per_job": round(ms / 6, 4),
+        # priced at what the sweep really moves (PMC, profiles/r02_opbench_pmc_traffic.json: 3.26 GB read + 3.22 GB written = 6.0 B/voxel;
+        # an upper bound of 9 B/voxel flattered the figure in round 2)
+        report("M6", "part_carve, six 90-degree jobs (one fused sweep)", ms, 6, {"jobs": 6, "ms_per_job": round(ms / 6, 4),
                                                                                  "reference_execution_B_per_voxel": 36})
         for b in (d_ms, d_mc, d_out):
             b.free()
@@ -130,6 +142,31 @@ def main():
         st_fn = lambda: L.check(lib.pb3d_component_stats_dev(L.ctx(), C.c_void_p(d_lab.ptr), S, S, S, ncomp.value, bbox, cnt, csum))
         report("A9", "component statistics (bbox, count, coordinate sums)", timeit(st_fn, 2, warm=1), 4)
         d_lab.free()
+    if "N2" in ops:
+        # the N1 / N2 kernels of the notebook-1 chain on the carved colour grid: orientation (transpose + flip: 3 B read, 3 B written),
+        # the four in-place extrusions (a column scan reads at most the 3 B/voxel it crosses and writes `depth` cells), labelling WITH the
+        # component statistics (3 B read + 4 B of int32 labels written), recolouring (4 B of labels read, flagged voxels written)
+        d_o = dev.DeviceBuffer(nvox * 3)
+        report("N2", "orient (transpose(2,1,0,3) + flip)", timeit(lambda: L.check(lib.pb3d_orient_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, C.c_void_p(d_o.ptr))), a.reps), 6)
+        d_v = dev.DeviceBuffer(S * S)
+        L.check(lib.pb3d_dev_memset(L.ctx(), C.c_void_p(d_v.ptr), 1, S * S))
+        fc = np.array(pb3d.PART_COLORS["windows"], np.uint8)
+        for axis, nm in ((2, "z"), (0, "x")):
+            for plus in (1, 0):
+                fn = lambda: L.check(lib.pb3d_extrude_dev(L.ctx(), C.c_void_p(d_o.ptr), S, S, S, C.c_void_p(d_v.ptr), S, axis, plus, 10, L.p_u8(fc), C.c_void_p(d_o.ptr)))
+                report("N2", f"extrude_from_surface axis {axis} {'+' if plus else '-'} depth 10, in place (k_extrude_{nm})", timeit(fn, a.reps), 3)
+        from pb3d.voxel_carving_utils import _label_stats
+        col = np.array(pb3d.PART_COLORS["full_building"], np.uint8)
+        d_lab = dev.DeviceBuffer(nvox * 4)
+        out = {}
+        def lab_fn():
+            out["n"] = _label_stats(d_col, (S, S, S), col, d_lab)[0]
+        report("N2", "connected components of one colour + statistics (one pass, one round trip)", timeit(lab_fn, 2, warm=1), 7, {"components": out["n"]})
+        flags = np.ones(max(1, out["n"]), np.uint8)
+        fn = lambda: L.check(lib.pb3d_recolor_components_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), max(1, out["n"]), L.p_u8(fc), C.c_void_p(d_o.ptr)))
+        report("N2", "recolor_backward_components: recolour pass (k_recolor_flagged)", timeit(fn, 2, warm=1), 4)
+        for b in (d_o, d_v, d_lab):
+            b.free()
     if "M7" in ops or "M8" in ops:
         cols = np.ascontiguousarray(np.array(list(pb3d.PART_COLORS.values()), np.uint8))
         n = C.c_int64(0)
