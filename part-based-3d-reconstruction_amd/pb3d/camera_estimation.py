@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["compute_partwise_iou", "CameraObjective", "projection_iou_by_part"]
+__all__ = ["compute_partwise_iou", "CameraObjective", "projection_iou_by_part", "random_search", "coordinate_descent", "powell_search"]
 
 
 def partwise_iou_counts(proj_mask, gt_mask, colors):
@@ -201,3 +201,98 @@ def projection_iou_by_part(voxel_grid, part_colors, image, cam_params):
     finally:
         for b in bufs:
             b.free()
+
+
+# =====================================================================================================
+# N4: the search loops of launch_smart_aligner as drivers over CameraObjective.evaluate_batch
+# (reference utils/camera_estimation.py:606-650 random, :652-686 coordinate descent, :688-726 Powell).
+# A parameter set is the dict get_params() builds there (:528-542): cam_pos / target float64 arrays, f / cx / cy floats.
+# =====================================================================================================
+_KEYS = ("cam_x", "cam_y", "cam_z", "target_x", "target_y", "target_z", "f", "cx", "cy")        # the slider order (:505-518)
+
+
+def _snap(p):
+    q = dict(p)
+    q["cam_pos"] = np.array(p["cam_pos"], copy=True); q["target"] = np.array(p["target"], copy=True)
+    return q
+
+
+def random_search(objective, base, steps, rng=None, lock_xy_equal=False):
+    """Random Search button (:606-650): `steps` trials around `base` (never around the best so far), uniform in +-(50, 50, 100) for the
+    camera and the target, +-50 for f, +-20 for cx / cy, drawn from `rng` (default: the global np.random, as upstream) in upstream's
+    order; the best of base and trials by strict `>`.  ALL trials are ONE projection + IoU launch.  Returns (best_params, best_iou)."""
+    rng = np.random if rng is None else rng
+    step_cam = np.array([50, 50, 100]); step_tgt = np.array([50, 50, 100])
+    trials = []
+    for _ in range(int(steps)):
+        t = dict(base)
+        t["cam_pos"] = base["cam_pos"] + rng.uniform(-1, 1, 3) * step_cam
+        t["target"] = base["target"] + rng.uniform(-1, 1, 3) * step_tgt
+        t["f"] = base["f"] + rng.uniform(-1, 1) * 50
+        t["cx"] = base["cx"] + rng.uniform(-1, 1) * 20
+        t["cy"] = base["cy"] + rng.uniform(-1, 1) * 20
+        if lock_xy_equal:
+            t["cam_pos"][:2] = t["target"][:2]
+        trials.append(t)
+    vals = objective.evaluate_batch([base] + trials)
+    best_iou, best_p = -vals[0], dict(base)
+    for t, v in zip(trials, vals[1:]):
+        if -v > best_iou:
+            best_iou, best_p = -v, dict(t)
+    return best_p, best_iou
+
+
+def coordinate_descent(objective, base, rounds, lock_xy_equal=False):
+    """Coordinate Descent button (:652-686): per round the +-20 trials of the nine parameters in slider order, the FIRST improvement
+    (strict `>`) becomes the new best and ends the round.  Upstream's trial dicts are shallow copies, so the camera / target ARRAYS
+    are shared between the best set and every trial and are stepped in place: the -20 trial of an array entry really moves it, the
+    +20 trial moves it back (to fl(fl(x - 20) + 20): the value upstream continues with), and only f / cx / cy are ever tried at
+    +20.  That sequence does not depend on the IoUs until an improvement ends it, so a round's trials are laid out first and
+    evaluated in ONE launch.  Returns (best_params, best_iou)."""
+    best_p = _snap(base)
+    best_iou = -objective.evaluate_batch([best_p])[0]
+    for _ in range(int(rounds)):
+        cam = best_p["cam_pos"].copy(); tgt = best_p["target"].copy()          # the shared arrays as the round steps them
+        trials = []
+        for k in _KEYS:
+            for delta in (-20, 20):
+                t = dict(best_p)
+                if k.startswith("cam_") and not lock_xy_equal:
+                    cam["xyz".index(k[-1])] += delta
+                elif k.startswith("target_"):
+                    tgt["xyz".index(k[-1])] += delta
+                    if lock_xy_equal and k in ("target_x", "target_y"):
+                        cam["xyz".index(k[-1])] += delta
+                elif k in ("f", "cx", "cy"):
+                    t[k] = best_p[k] + delta
+                else:
+                    continue
+                t["cam_pos"] = cam.copy(); t["target"] = tgt.copy()
+                trials.append(t)
+        vals = objective.evaluate_batch(trials)
+        for t, v in zip(trials, vals):
+            if -v > best_iou:
+                best_iou, best_p = -v, t
+                break
+        else:
+            # no improvement: the arrays keep whatever the in-place steps left in them (the scalars are untouched)
+            best_p = dict(best_p); best_p["cam_pos"] = cam; best_p["target"] = tgt
+    return best_p, best_iou
+
+
+def powell_search(objective, base, maxiter, minimize, lock_xy_equal=False):
+    """Powell button (:688-726) with the caller's minimiser (upstream: `minimize(obj, x0, method='Powell', options=...)`): the
+    objective is CameraObjective.__call__ on from_vector(x) (:586-595).  Sequential by nature -- one camera per evaluation.
+    Returns (params, iou)."""
+    base = _snap(base)
+    if lock_xy_equal:
+        x0 = np.array([base["cam_pos"][2], base["target"][2], base["f"], base["cx"], base["cy"]])
+        tx, ty = base["target"][0], base["target"][1]
+        from_vec = lambda x: {"cam_pos": np.array([tx, ty, x[0]]), "target": np.array([tx, ty, x[1]]), "f": x[2], "cx": x[3], "cy": x[4]}
+    else:
+        x0 = np.concatenate([base["cam_pos"], base["target"], [base["f"], base["cx"], base["cy"]]])
+        from_vec = lambda x: {"cam_pos": x[:3], "target": x[3:6], "f": x[6], "cx": x[7], "cy": x[8]}
+    res = minimize(lambda x: objective(from_vec(x)), x0, method="Powell",
+                   options={"maxiter": int(maxiter), "maxfev": int(maxiter) * 10, "xtol": 1e-3, "ftol": 1e-3, "disp": False})
+    p = from_vec(res.x)
+    return p, -objective(p)

@@ -46,3 +46,43 @@ def pb3d_gpu():
     assert pb3d._lib.device_count() >= 1, "no MI355X visible"
     pb3d._lib.ctx()
     return pb3d
+
+
+# ---- N4 search loops: shared between the CPU test (oracle objective) and the GPU test (CameraObjective) --------------------------
+def n4_loop_cases():
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "n4_search_loops.json")))
+    front = np.load(os.path.join(GOLDEN, "n4_search_loops.npz"))["front_Akbar"]
+    grid = np.load(os.path.join(GOLDEN, "stored_Akbar_voxel_grid.npz"))["voxel_grid"]
+    return meta["cases"], front, grid
+
+
+def n4_params(sl, lock):
+    """get_params() of launch_smart_aligner (reference utils/camera_estimation.py:528-542) from recorded slider values"""
+    cam = np.array([sl[f"cam_{c}"] for c in "xyz"]); tgt = np.array([sl[f"target_{c}"] for c in "xyz"])
+    if lock:
+        cam[0], cam[1] = tgt[0], tgt[1]
+    return {"cam_pos": cam, "target": tgt, "f": sl["f"], "cx": sl["cx"], "cy": sl["cy"]}
+
+
+def n4_sliders(p):
+    d = {f"cam_{c}": float(v) for c, v in zip("xyz", p["cam_pos"])}
+    d.update({f"target_{c}": float(v) for c, v in zip("xyz", p["target"])})
+    d.update({"f": float(p["f"]), "cx": float(p["cx"]), "cy": float(p["cy"])})
+    return d
+
+
+def n4_run_case(case, objective, minimize=None):
+    """drive the three buttons like the fixture generator did; returns the slider states after each"""
+    from pb3d.camera_estimation import random_search, coordinate_descent, powell_search
+    lock = case["lock_xy_equal"]
+    np.random.seed(case["seed"])
+    best, _ = random_search(objective, n4_params(case["start"], lock), case["random_steps"], lock_xy_equal=lock)
+    s1 = n4_sliders(best)
+    best, _ = coordinate_descent(objective, n4_params(s1, lock), case["coord_steps"], lock_xy_equal=lock)
+    s2 = n4_sliders(best)
+    s3 = None
+    if minimize is not None:
+        best, _ = powell_search(objective, n4_params(s2, lock), case["powell_maxiter"], minimize, lock_xy_equal=lock)
+        s3 = n4_sliders(best)
+    return s1, s2, s3

@@ -1339,3 +1339,26 @@ def test_global_carve_fused_chain_other_angles(pb3d_gpu, oracle, golden):
     for name in ("f4_Akbar_64", "f4_Bibi_64", "f4_Taj_96"):
         g = golden(name)
         assert np.array_equal(pb3d_gpu.global_carve(g["binary"], g["ext"], 45), g["global_carve_45"]), name
+
+
+def test_search_loops_batched_equal_the_reference_buttons(pb3d_gpu):
+    """Row N4, the loops: Random Search (all trials ONE launch), Coordinate Descent (a round's 18 trials ONE launch, first improvement
+    wins) and Powell over the resident CameraObjective leave exactly the parameters the reference's buttons left (fixture: headless
+    drive of launch_smart_aligner with a seeded np.random, tools/gen_golden_n4_loops.py)."""
+    from scipy.optimize import minimize
+    from conftest import n4_loop_cases, n4_run_case
+    from pb3d.camera_estimation import CameraObjective
+    cases, front, grid = n4_loop_cases()
+    PC = pb3d_gpu.PART_COLORS
+    for case in cases:
+        parts = case["parts"]
+        pts, cols = pb3d_gpu.get_voxel_points_by_parts(grid, PC, parts)
+        seg = pb3d_gpu.mask_parts_from_image(front, PC, parts)
+        obj = CameraObjective(pts, cols, seg, {p: PC[p] for p in parts})
+        try:
+            s1, s2, s3 = n4_run_case(case, obj, minimize)
+        finally:
+            obj.close()
+        assert s1 == case["after_random"], (parts, "random")
+        assert s2 == case["after_coord"], (parts, "coord")
+        assert s3 == case["after_powell"], (parts, "powell")

@@ -154,3 +154,34 @@ def test_result_pool_reuses_only_released_memory():
     finally:
         hm.set_result_pool(0)
         hm.set_result_pool(before)
+
+
+def test_search_loop_drivers_reproduce_the_reference_buttons(oracle):
+    """Row N4's loops (pb3d.camera_estimation.random_search / coordinate_descent / powell_search, reference
+    utils/camera_estimation.py:606-726) driven with the ORACLE's objective: the parameters each button of the reference's widget left
+    behind (tools/gen_golden_n4_loops.py: headless drive with a seeded np.random), bit for bit -- the random trials around the base,
+    the in-place stepping of the shared camera / target arrays in the coordinate loop, the first-improvement rule, Powell through the
+    caller's minimiser.  (The GPU test runs the same drivers on CameraObjective.evaluate_batch.)"""
+    from scipy.optimize import minimize
+    from conftest import n4_loop_cases, n4_run_case
+    cases, front, grid = n4_loop_cases()
+    PC = oracle.PART_COLORS
+
+    class Objective:
+        def __init__(self, parts):
+            self.pts, self.cols = oracle.get_voxel_points_by_parts(grid, PC, parts)
+            self.seg = oracle.mask_parts_from_image(front, PC, parts)
+            self.sel = {p: PC[p] for p in parts}
+
+        def __call__(self, p):
+            H, W = self.seg.shape[:2]
+            return oracle.camera_objective(self.pts, self.cols, self.seg, self.sel, p, H, W)
+
+        def evaluate_batch(self, ps):
+            return [self(p) for p in ps]
+
+    for case in cases:
+        s1, s2, s3 = n4_run_case(case, Objective(case["parts"]), minimize)
+        assert s1 == case["after_random"], (case["parts"], "random")
+        assert s2 == case["after_coord"], (case["parts"], "coord")
+        assert s3 == case["after_powell"], (case["parts"], "powell")
