@@ -267,6 +267,20 @@ int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int3
 int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                           const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                           int64_t* carved_counts, int* took);
+/* The rest of the notebook-1 chain on the 1-byte LABEL form of a palette grid (row N3; label 0 = empty, the others index a palette):
+ * the same kernels with one byte per voxel -- components of the voxels that carry `value`, the fused component loop, extrusion
+ * (fill_label < 0: clear), recolouring and the output orientation.  Expanding a result with the palette gives the bytes of the RGB
+ * entry (tests: label chain == RGB chain == the reference's stage digests). */
+int pb3d_label_value_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, uint8_t value, int32_t* d_labels,
+                               int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum, int* stats_valid);
+int pb3d_guided_carve_label_dev(pb3d_ctx* ctx, uint8_t* d_grid_lab, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
+                                const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
+                                int64_t* carved_counts, int* took);
+int pb3d_extrude_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
+                           int axis, int plus, int depth, int fill_label, uint8_t* d_out);
+int pb3d_recolor_components_label_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                                      uint8_t new_label, uint8_t* d_grid_lab);
+int pb3d_orient_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t W, int64_t H, int64_t D, uint8_t* d_out);
 /* *d_count (a device int64 the caller has zeroed) += number of non-zero bytes of d_bytes[0..n): the "carved voxels" figure of
  * left_right_guided_carve's log (reference utils/voxel_carving_utils.py:197), without a host round trip per component. */
 int pb3d_count_nonzero_dev(pb3d_ctx* ctx, const uint8_t* d_bytes, int64_t n, int64_t* d_count);

@@ -67,11 +67,13 @@ typedef u32 u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
 // start is carried across windows and chunks.
 constexpr int kChunkVox = 1024;
 
+// C = 1: the grid is a 1-byte LABEL volume (row N3) and color24 the label -- a lane's 16 voxels are one 16-byte load.
+template <int C>
 __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 rows, int A2, int P, u32 color24, u64* __restrict__ bits,
                                                   int* __restrict__ parent) {
     const int lane = threadIdx.x & 63;
     const u64 le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-    const i64 nbytes = 3 * rows * (i64)A2;
+    const i64 nbytes = C * rows * (i64)A2;
     for (i64 rw = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); rw < rows; rw += (i64)gridDim.x * 4) {
         const u32 row = (u32)__builtin_amdgcn_readfirstlane((int)rw);
         const u32 base = row * (u32)A2;
@@ -80,7 +82,22 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
             // ---- 16 membership bits of this lane's voxels c0 + 16 lane .. + 15
             const int v = c0 + 16 * lane;
             u32 m16 = 0;
-            if (v < A2) {
+            if (C == 1 && v < A2) {
+                const i64 boff = (i64)base + v;
+                u32 w[4];
+                if (boff + 16 <= nbytes) { const u32x4a1 t = *(const u32x4a1*)(grid + boff); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u32 t = 0;
+                        for (int b = 0; b < 4; ++b) { const i64 o = boff + 4 * k + b; if (o < nbytes) t |= (u32)grid[o] << (8 * b); }
+                        w[k] = t;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m16 |= (u32)(((w[i >> 2] >> (8 * (i & 3))) & 0xffu) == color24) << i;
+                if (v + 16 > A2) m16 &= (1u << (A2 - v)) - 1u;
+            } else if (v < A2) {
                 const i64 boff = 3 * ((i64)base + v);
                 u32 w[13];
                 w[12] = 0u;
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(256) void k_fin_stats_init(int cap, int* __restrict
 
 static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
                             int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum,
-                            int* stats_valid) {
+                            int* stats_valid, int C = 3) {
     PB3D_REQUIRE(ctx && color && ncomp && A0 >= 0 && A1 >= 0 && A2 >= 0, "pb3d_label_color: bad argument");
     const i64 n = A0 * A1 * A2;
     *ncomp = 0;
@@ -401,12 +418,16 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     u32* chunk_count = (u32*)chunks;
     u32* chunk_base = chunk_count + nchunks;
     i64* total = (i64*)((char*)chunks + (((size_t)nchunks * 8 + 7) & ~(size_t)7));
-    const u32 color24 = (u32)color[0] | ((u32)color[1] << 8) | ((u32)color[2] << 16);
+    const u32 color24 = C == 1 ? (u32)color[0] : ((u32)color[0] | ((u32)color[1] << 8) | ((u32)color[2] << 16));
     const pb3d_magic mP = pb3d_make_magic((u32)P), m1 = pb3d_make_magic((u32)A1);
     int* parent = (int*)d_labels;
 
-    hipLaunchKernelGGL(k_ccl_init, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24, (u64*)bits,
-                       parent);
+    if (C == 1)
+        hipLaunchKernelGGL(k_ccl_init<1>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24,
+                           (u64*)bits, parent);
+    else
+        hipLaunchKernelGGL(k_ccl_init<3>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24,
+                           (u64*)bits, parent);
     PB3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ccl_merge, dim3(pb3d_stream_blocks(ctx, nwords, 256, 16)), dim3(256), 0, ctx->stream, (const u64*)bits, nwords, mP, m1, (int)A0,
                        (int)A1, (int)A2, parent);
@@ -474,4 +495,13 @@ extern "C" int pb3d_label_color_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_r
                                           int64_t* coord_sum, int* stats_valid) {
     PB3D_REQUIRE(stats_valid != nullptr, "pb3d_label_color_stats: null output");
     return label_color_impl(ctx, d_grid_rgb, A0, A1, A2, color, d_labels, ncomp, cap, bbox_lo_hi, count, coord_sum, stats_valid);
+}
+
+// the same on a 1-byte LABEL volume (row N3): components of the voxels whose label is `value`
+extern "C" int pb3d_label_value_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, uint8_t value,
+                                          int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count,
+                                          int64_t* coord_sum, int* stats_valid) {
+    PB3D_REQUIRE(stats_valid != nullptr, "pb3d_label_value_stats: null output");
+    const uint8_t c3[3] = {value, 0, 0};
+    return label_color_impl(ctx, d_grid_lab, A0, A1, A2, c3, d_labels, ncomp, cap, bbox_lo_hi, count, coord_sum, stats_valid, 1);
 }

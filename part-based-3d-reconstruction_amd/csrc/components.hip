@@ -116,11 +116,15 @@ __global__ __launch_bounds__(256) void k_comp_paste(const u8* __restrict__ color
 }
 
 // recolor_backward_components (reference :263-265): voxels whose component is flagged get new_color
+// (C = 1: the grid is a 1-byte label volume, r the new label)
 __global__ __launch_bounds__(256) void k_recolor_flagged(const int* __restrict__ labels, const u8* __restrict__ comp_flag, i64 n, u8 r,
-                                                         u8 g, u8 b, u8* __restrict__ grid) {
+                                                         u8 g, u8 b, u8* __restrict__ grid, int C) {
     for (i64 v = (i64)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (i64)gridDim.x * blockDim.x) {
         const int L = labels[v];
-        if (L > 0 && comp_flag[L - 1]) { grid[3 * v] = r; grid[3 * v + 1] = g; grid[3 * v + 2] = b; }
+        if (L > 0 && comp_flag[L - 1]) {
+            if (C == 1) grid[v] = r;
+            else { grid[3 * v] = r; grid[3 * v + 1] = g; grid[3 * v + 2] = b; }
+        }
     }
 }
 
@@ -129,17 +133,17 @@ __global__ __launch_bounds__(256) void k_recolor_flagged(const int* __restrict__
 // cells from there, inside the grid, are painted where valid[x,y].
 // (src and dst may be the same volume: a column is scanned and painted by one wavefront / one thread)
 __global__ __launch_bounds__(256) void k_extrude_z(const u8* src, u8* dst, const u8* __restrict__ valid_wh,
-                                                   i64 W, i64 H, i64 D, int plus, int depth, int has_color, u8 cr, u8 cg, u8 cb) {
+                                                   i64 W, i64 H, i64 D, int plus, int depth, int has_color, u8 cr, u8 cg, u8 cb, int C) {
     const int lane = threadIdx.x & 63;
     const i64 col = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= W * H) return;
     if (!valid_wh[col]) return;     // wave-uniform: nothing is painted in this column, so its surface is not looked for either
-    const u8* s = src + col * D * 3;
+    const u8* s = src + col * D * C;
     i64 start = plus ? 0 : D - 1;   // argmax of an all-zero column is index 0 (of the possibly reversed view)
     for (i64 base = 0; base < D; base += 64) {
         const i64 j = base + lane;                     // position along the scan direction
         const i64 z = plus ? j : D - 1 - j;
-        const bool on = j < D && (s[3 * z] | s[3 * z + 1] | s[3 * z + 2]);
+        const bool on = j < D && (C == 1 ? s[z] : (s[3 * z] | s[3 * z + 1] | s[3 * z + 2]));
         const u64 bal = __ballot(on);
         if (bal) {
             const i64 jj = base + (__ffsll((unsigned long long)bal) - 1);
@@ -150,8 +154,9 @@ __global__ __launch_bounds__(256) void k_extrude_z(const u8* src, u8* dst, const
     for (int d = lane; d < depth; d += 64) {
         const i64 z = plus ? start + d : start - d;
         if (z < 0 || z >= D) continue;
-        u8* o = dst + (col * D + z) * 3;
-        o[0] = has_color ? cr : (u8)0; o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0;
+        u8* o = dst + (col * D + z) * C;
+        o[0] = has_color ? cr : (u8)0;
+        if (C == 3) { o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0; }
     }
 }
 
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void k_extrude_z(const u8* src, u8* dst, const
 // [y, z] exactly as upstream indexes its (H,W) mask with the z coordinate (which needs D == W).
 __global__ __launch_bounds__(256) void k_extrude_x(const u8* src, u8* dst, const u8* __restrict__ valid_hw,
                                                    i64 W, i64 H, i64 D, i64 Wmask, int plus, int depth, int has_color, u8 cr, u8 cg,
-                                                   u8 cb) {
+                                                   u8 cb, int C) {
     const i64 n = H * D;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         const i64 y = i / D, z = i - y * D;
@@ -167,14 +172,15 @@ __global__ __launch_bounds__(256) void k_extrude_x(const u8* src, u8* dst, const
         i64 start = plus ? 0 : W - 1;
         for (i64 j = 0; j < W; ++j) {
             const i64 x = plus ? j : W - 1 - j;
-            const u8* p = src + ((x * H + y) * D + z) * 3;
-            if (p[0] | p[1] | p[2]) { start = x; break; }
+            const u8* p = src + ((x * H + y) * D + z) * C;
+            if (C == 1 ? p[0] : (p[0] | p[1] | p[2])) { start = x; break; }
         }
         for (int d = 0; d < depth; ++d) {
             const i64 x = plus ? start + d : start - d;
             if (x < 0 || x >= W) continue;
-            u8* o = dst + ((x * H + y) * D + z) * 3;
-            o[0] = has_color ? cr : (u8)0; o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0;
+            u8* o = dst + ((x * H + y) * D + z) * C;
+            o[0] = has_color ? cr : (u8)0;
+            if (C == 3) { o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0; }
         }
     }
 }
@@ -232,6 +238,65 @@ __global__ __launch_bounds__(256) void k_stats_init(i64 ncomp, int* __restrict__
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < ncomp; k += (i64)gridDim.x * blockDim.x) {
         for (int a = 0; a < 3; ++a) { bbox[6 * k + a] = 0x7fffffff; bbox[6 * k + 3 + a] = -1; }
         for (int a = 0; a < 4; ++a) cnt_sum[4 * k + a] = 0ull;
+    }
+}
+
+// ... of a 1-byte label volume (row N3): out[z, H-1-y, x] = grid[x, y, z]; 64 x 64 byte tiles, dword rows on both sides where aligned
+__global__ __launch_bounds__(256) void k_orient_label(const u8* __restrict__ grid, u8* __restrict__ out, i64 W, i64 H, i64 D) {
+    __shared__ u8 t[64][64 + 4];
+    const i64 x0 = (i64)blockIdx.x * 64, z0 = (i64)blockIdx.y * 64, y = blockIdx.z;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int xl = i >> 6, zl = i & 63;
+        const i64 x = x0 + xl, z = z0 + zl;
+        t[xl][zl] = (x < W && z < D) ? grid[(x * H + y) * D + z] : (u8)0;
+    }
+    __syncthreads();
+    const i64 yb = H - 1 - y;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int zl = i >> 6, xl = i & 63;
+        const i64 x = x0 + xl, z = z0 + zl;
+        if (x < W && z < D) out[(z * H + yb) * W + x] = t[xl][zl];
+    }
+}
+
+// The same permutation for grids whose x and z extents are multiples of 128 (Taj 512 x 278 x 512, 1024^3): 128 x 128-pixel tiles, so a
+// source row (fixed x, 128 z) and a destination row (fixed z, 128 x) are both 384 bytes = THREE WHOLE 128-byte lines, moved as 16-byte
+// vectors; the 3-byte pixels are transposed by byte gathers from LDS (row pitch 400 bytes).  k_orient4's 32-pixel tiles cut every row
+// into 96-byte pieces that start mid-line: 0.30 of the HBM peak at Taj 512, 0.39 at 1024^3.
+constexpr int kOT = 128, kOPitch = 400;
+__global__ __launch_bounds__(256) void k_orient128(const u8* __restrict__ grid, u8* __restrict__ out, i64 W, i64 H, i64 D) {
+    typedef u32 u32x4o __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) u8 ot[];             // kOT rows of kOPitch bytes
+    const i64 x0 = (i64)blockIdx.x * kOT, z0 = (i64)blockIdx.y * kOT, y = blockIdx.z;
+    u32x4o v[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {                                      // 128 source rows x 24 units of 16 bytes
+        const int i = threadIdx.x + 256 * j, xl = i / 24, k = i - xl * 24;
+        v[j] = __builtin_nontemporal_load((const u32x4o*)(grid + (((x0 + xl) * H + y) * D + z0) * 3 + 16 * k));
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const int i = threadIdx.x + 256 * j, xl = i / 24, k = i - xl * 24;
+        *(u32x4o*)(ot + xl * kOPitch + 16 * k) = v[j];
+    }
+    __syncthreads();
+    const i64 yb = H - 1 - y;
+#pragma unroll 2
+    for (int j = 0; j < 12; ++j) {                                      // 128 destination rows x 24 units
+        const int i = threadIdx.x + 256 * j, zl = i / 24, k = i - zl * 24;
+        u32 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32 d = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int bb = 16 * k + 4 * q + b, xl = (bb * 21846) >> 16, c = bb - 3 * xl;      // bb / 3 for bb < 384
+                d |= (u32)ot[xl * kOPitch + 3 * zl + c] << (8 * b);
+            }
+            w[q] = d;
+        }
+        u32x4o r; r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3];
+        __builtin_nontemporal_store(r, (u32x4o*)(out + (((z0 + zl) * H + yb) * W + x0) * 3 + 16 * k));
     }
 }
 
@@ -317,8 +382,8 @@ int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int3
     return PB3D_OK;
 }
 
-int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
-                                const uint8_t new_color[3], uint8_t* d_grid_rgb) {
+static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                        const uint8_t new_color[3], uint8_t* d_grid_rgb, int C) {
     PB3D_REQUIRE(ctx && new_color && nvox >= 0 && ncomp >= 0, "pb3d_recolor_components: bad argument");
     if (nvox == 0 || ncomp == 0) return PB3D_OK;
     PB3D_REQUIRE(d_labels && comp_flag && d_grid_rgb, "pb3d_recolor_components: null buffer");
@@ -327,7 +392,28 @@ int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t 
     PB3D_HIP(hipMemcpyAsync(f, comp_flag, (size_t)ncomp, hipMemcpyHostToDevice, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));   // comp_flag is a caller-owned host buffer
     hipLaunchKernelGGL(k_recolor_flagged, dim3(pb3d_stream_blocks(ctx, nvox, 256, 8)), dim3(256), 0, ctx->stream, d_labels, (const u8*)f, nvox,
-                       new_color[0], new_color[1], new_color[2], d_grid_rgb);
+                       new_color[0], new_color[1], new_color[2], d_grid_rgb, C);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
+}
+
+int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                                const uint8_t new_color[3], uint8_t* d_grid_rgb) {
+    return recolor_impl(ctx, d_labels, nvox, comp_flag, ncomp, new_color, d_grid_rgb, 3);
+}
+
+int pb3d_recolor_components_label_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                                      uint8_t new_label, uint8_t* d_grid_lab) {
+    const uint8_t c3[3] = {new_label, 0, 0};
+    return recolor_impl(ctx, d_labels, nvox, comp_flag, ncomp, c3, d_grid_lab, 1);
+}
+
+int pb3d_orient_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t W, int64_t H, int64_t D, uint8_t* d_out) {
+    PB3D_REQUIRE(ctx && W >= 0 && H >= 0 && D >= 0, "pb3d_orient: bad shape");
+    if (W * H * D == 0) return PB3D_OK;
+    PB3D_REQUIRE(d_grid_lab && d_out && d_grid_lab != d_out, "pb3d_orient: null or aliased buffer");
+    PB3D_REQUIRE(H <= 65535 && (D + 63) / 64 <= 65535, "pb3d_orient: grid too large");
+    hipLaunchKernelGGL(k_orient_label, dim3((unsigned)((W + 63) / 64), (unsigned)((D + 63) / 64), (unsigned)H), dim3(256), 0, ctx->stream, d_grid_lab, d_out, W, H, D);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
@@ -337,6 +423,15 @@ int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t
     if (W * H * D == 0) return PB3D_OK;
     PB3D_REQUIRE(d_grid_rgb && d_out && d_grid_rgb != d_out, "pb3d_orient: null or aliased buffer");
     PB3D_REQUIRE(H <= 65535 && (D + 31) / 32 <= 65535, "pb3d_orient: grid too large");
+    if (W % kOT == 0 && D % kOT == 0 && ((((uintptr_t)d_grid_rgb) | ((uintptr_t)d_out)) & 15u) == 0 && ctx->tune_misc[2] != 5) {
+        if (!ctx->orient_lds_set) {
+            PB3D_HIP(hipFuncSetAttribute((const void*)k_orient128, hipFuncAttributeMaxDynamicSharedMemorySize, kOT * kOPitch));
+            ctx->orient_lds_set = true;
+        }
+        hipLaunchKernelGGL(k_orient128, dim3((unsigned)(W / kOT), (unsigned)(D / kOT), (unsigned)H), dim3(256), kOT * kOPitch, ctx->stream, d_grid_rgb, d_out, W, H, D);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
     dim3 grid((unsigned)((W + 31) / 32), (unsigned)((D + 31) / 32), (unsigned)H);
     if (W % 4 == 0 && D % 4 == 0 && ((((uintptr_t)d_grid_rgb) | ((uintptr_t)d_out)) & 3u) == 0)
         hipLaunchKernelGGL(k_orient4, grid, dim3(256), 0, ctx->stream, d_grid_rgb, d_out, W, H, D);
@@ -346,27 +441,38 @@ int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t
     return PB3D_OK;
 }
 
-int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
-                     int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out) {
+static int extrude_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
+                        int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out, int C) {
     PB3D_REQUIRE(ctx && W >= 0 && H >= 0 && D >= 0, "pb3d_extrude: bad shape");
     PB3D_REQUIRE(axis == 0 || axis == 2, "pb3d_extrude: axis must be 0 or 2");
     const i64 n = W * H * D;
     if (n == 0) return PB3D_OK;
     PB3D_REQUIRE(d_grid_rgb && d_valid && d_out, "pb3d_extrude: null buffer");
     // d_out == d_grid_rgb: in place (a chain of extrusions on a resident grid then moves no volume at all)
-    if (d_out != d_grid_rgb) PB3D_HIP(hipMemcpyAsync(d_out, d_grid_rgb, (size_t)n * 3, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_out != d_grid_rgb) PB3D_HIP(hipMemcpyAsync(d_out, d_grid_rgb, (size_t)n * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
     if (depth <= 0) return PB3D_OK;
     const u8 cr = fill_color ? fill_color[0] : 0, cg = fill_color ? fill_color[1] : 0, cb = fill_color ? fill_color[2] : 0;
     if (axis == 2) {
         hipLaunchKernelGGL(k_extrude_z, dim3((unsigned)((W * H + 3) / 4)), dim3(256), 0, ctx->stream, d_grid_rgb, d_out, d_valid, W, H, D,
-                           plus ? 1 : 0, depth, fill_color ? 1 : 0, cr, cg, cb);
+                           plus ? 1 : 0, depth, fill_color ? 1 : 0, cr, cg, cb, C);
     } else {
         PB3D_REQUIRE(valid_w >= D, "pb3d_extrude: axis-0 extrusion indexes the (H,W) mask with z and needs W_mask >= D");
         hipLaunchKernelGGL(k_extrude_x, dim3(pb3d_stream_blocks(ctx, H * D, 256, 8)), dim3(256), 0, ctx->stream, d_grid_rgb, d_out, d_valid, W,
-                           H, D, valid_w, plus ? 1 : 0, depth, fill_color ? 1 : 0, cr, cg, cb);
+                           H, D, valid_w, plus ? 1 : 0, depth, fill_color ? 1 : 0, cr, cg, cb, C);
     }
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
+}
+
+int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
+                     int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out) {
+    return extrude_impl(ctx, d_grid_rgb, W, H, D, d_valid, valid_w, axis, plus, depth, fill_color, d_out, 3);
+}
+
+int pb3d_extrude_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
+                           int axis, int plus, int depth, int fill_label, uint8_t* d_out) {
+    const uint8_t c3[3] = {(uint8_t)(fill_label < 0 ? 0 : fill_label), 0, 0};
+    return extrude_impl(ctx, d_grid_lab, W, H, D, d_valid, valid_w, axis, plus, depth, fill_label < 0 ? nullptr : c3, d_out, 1);
 }
 
 }  // extern "C"

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_crop_cells(const CropDesc* __restrict__
 // other workgroup of the launch touches those voxels (disjoint boxes within a batch, disjoint planes within a component).
 __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* dst_rgb, const int* __restrict__ labels, i64 H, i64 D,
                                                          const CropDesc* __restrict__ descs, int ncomp, const u8* __restrict__ masks,
-                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore) {
+                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C) {
     extern __shared__ u32 lds[];
     const int tid = threadIdx.x;
     int c = 0;
@@ -72,13 +72,13 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
     // this thread's cells: tid, tid + 512, ... -- (xs, zs) advanced without a division per cell
     const int dx = GTHREADS / Dc, dz = GTHREADS - dx * Dc;
     const int xs0 = tid / Dc, zs0 = tid - xs0 * Dc;
-    const i64 rowb = D * 3;                              // bytes from plane y to plane y + 1 of the grid
+    const i64 rowb = D * C;                              // bytes from plane y to plane y + 1 of the grid (C = 3 colours, 1 label)
     // Every loop below is latency-bound if written cell by cell (a dependent global load per iteration: the first version spent
     // 220 us on a dome crop): loads are issued eight at a time before any of them is used.
     {   // occupancy of the crop (any channel > 0, reference :190), 32 planes per cell, with the 0-degree carve (:124, first iteration)
         int xs = xs0, zs = zs0;
         for (int cell = tid; cell < ncell; cell += GTHREADS) {
-            const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * 3;
+            const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * C;
             u32 bits = 0;
             for (int q0 = 0; q0 < np; q0 += 8) {
                 u32 any[8];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
                 for (int k = 0; k < 8; ++k) {
                     const int q = q0 + k < np ? q0 + k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
                     const u8* v = p + (i64)q * rowb;
-                    any[k] = (u32)v[0] | (u32)v[1] | (u32)v[2];
+                    any[k] = C == 1 ? (u32)v[0] : ((u32)v[0] | (u32)v[1] | (u32)v[2]);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -132,13 +132,14 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
                 for (int k = 0; k < 8; ++k) lab[k] = ((todo >> (q0 + k)) & 1u) ? labels[v0 + (i64)(q0 + k) * D] : 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (lab[k] == d.id) { u8* o = dst_rgb + 3 * (v0 + (i64)(q0 + k) * D); o[0] = 0; o[1] = 0; o[2] = 0; }
+                    if (lab[k] == d.id) { u8* o = dst_rgb + C * (v0 + (i64)(q0 + k) * D); o[0] = 0; if (C == 3) { o[1] = 0; o[2] = 0; } }
             }
             if (restore) {          // boxes overlap somewhere: an EARLIER component may have cleared a voxel this crop keeps -- write it back (:200-201)
                 for (u32 kept = R & live; kept; kept &= kept - 1) {
                     const i64 v = v0 + (i64)__builtin_ctz(kept) * D;
-                    const u8* sv = src_rgb + 3 * v;
-                    if (sv[0] | sv[1] | sv[2]) { u8* o = dst_rgb + 3 * v; o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2]; }
+                    const u8* sv = src_rgb + C * v;
+                    if (C == 1) { if (sv[0]) dst_rgb[v] = sv[0]; }
+                    else if (sv[0] | sv[1] | sv[2]) { u8* o = dst_rgb + 3 * v; o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2]; }
                 }
             }
             xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
@@ -155,11 +156,9 @@ static bool boxes_overlap(const i64* a, const i64* b) {
 
 }  // namespace
 
-extern "C" {
-
-int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
-                          const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
-                          int64_t* carved_counts, int* took) {
+static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
+                             const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
+                             int64_t* carved_counts, int* took, int C) {
     PB3D_REQUIRE(ctx && took && W >= 0 && H >= 0 && D >= 0 && ncomp >= 0, "pb3d_guided_carve: bad argument");
     *took = 0;
     PB3D_REQUIRE(angle_interval > 0, "pb3d_guided_carve: angle_interval must be a positive integer (got %d)", angle_interval);
@@ -186,7 +185,7 @@ int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_l
         PB3D_HIP(hipFuncSetAttribute((const void*)k_crop_chain, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         ctx->guided_lds_set = true;
     }
-    const size_t nvox3 = (size_t)(W * H * D) * 3;
+    const size_t nvox3 = (size_t)(W * H * D) * (size_t)C;
     void *d_masks, *d_counts;
     PB3D_TRY(pb3d_scratch(ctx, 37, (size_t)mask_bytes + 16, &d_masks));
     PB3D_TRY(pb3d_scratch(ctx, 39, (size_t)ncomp * sizeof(unsigned long long), &d_counts));
@@ -278,7 +277,7 @@ int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_l
                 hipLaunchKernelGGL(k_crop_cells, gridc, dim3(256), 0, ctx->stream, (const CropDesc*)ddb, (const RotParams*)dpb, nrot, (u32*)dt);
             }
             hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
-                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0);
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C);
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");
@@ -292,6 +291,21 @@ int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_l
     PB3D_HIP(es);
     *took = 1;
     return PB3D_OK;
+}
+
+extern "C" {
+
+int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
+                          const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
+                          int64_t* carved_counts, int* took) {
+    return guided_carve_impl(ctx, d_grid_rgb, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, 3);
+}
+
+// the same on a 1-byte LABEL volume (row N3): occupancy = label != 0, cleared voxels get label 0
+int pb3d_guided_carve_label_dev(pb3d_ctx* ctx, uint8_t* d_grid_lab, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
+                                const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
+                                int64_t* carved_counts, int* took) {
+    return guided_carve_impl(ctx, d_grid_lab, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, 1);
 }
 
 }  // extern "C"

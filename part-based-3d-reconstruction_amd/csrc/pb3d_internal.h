@@ -28,6 +28,7 @@ struct pb3d_ctx {
     hipStream_t stream;
     bool wide_lds_set;          // hipFuncSetAttribute(max dynamic LDS) done for the wide rotate kernel on this device
     bool packed_lds_set;        // ... and for the packed 256-tile one
+    bool orient_lds_set;        // ... and for the 128-pixel orientation kernel (csrc/components.hip)
     bool guided_lds_set;        // ... and for the crop-chain kernel of left_right_guided_carve (csrc/guided.hip)
     // development knobs, read from the environment ONCE in pb3d_create (never on a launch path)
     int tune_rotate_tile;       // PB3D_ROTATE_TILE: 0 = choose, 64 / 128 / 256 = pin the generic-angle tile kernel

@@ -25,6 +25,7 @@ struct SelParams {
     u32 m2, m1;
     int s2a, s2b, s1a, s1b;
     int packed;        // 1: (a2, a1, a0) of a voxel fit 21 bits each (k_points_fill16 keeps per-group coordinates as one u64)
+    int labelsel;      // C == 1 with a label set (row N3: 1-byte label volumes): selected = label in the set (htab[label] == 2)
 };
 
 struct Magic { u32 m; int sa, sb; };
@@ -56,6 +57,11 @@ __device__ __forceinline__ i64 lattice_to_voxel(const SelParams& p, i64 li, i64*
 
 __device__ __forceinline__ bool selected(const SelParams& p, const u8* __restrict__ grid, i64 vox) {
     const u8* g = grid + vox * p.C;
+    if (p.labelsel) {
+        bool s = false;
+        for (int k = 0; k < p.ncolors; ++k) s |= g[0] == p.colors[k];
+        return s;
+    }
     if (p.ncolors > 0) {
         const u8 r = g[0], gg = g[1], b = g[2];
         bool s = false;
@@ -230,7 +236,7 @@ __device__ __forceinline__ u32 select16(const SelParams& p, const u32* htab, con
 }
 
 // occupancy grids (C == 1): the 16 voxels are one 16-byte load; selected = byte != 0
-__device__ __forceinline__ u32 select16_occ(const u8* __restrict__ grid, i64 v0, i64 nvox, u32 w[4]) {
+__device__ __forceinline__ u32 select16_occ(const u8* __restrict__ grid, i64 v0, i64 nvox, u32 w[4], const u32* htab = nullptr) {
     if (v0 + 16 <= nvox) {
         const u32x4v t = *(const u32x4v*)(grid + v0);
         w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
@@ -243,6 +249,13 @@ __device__ __forceinline__ u32 select16_occ(const u8* __restrict__ grid, i64 v0,
         }
     }
     u32 bits = 0;
+    if (htab) {          // label volumes: one table read per voxel (htab[label] == 2 for the labels of the set)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bits |= (u32)(htab[(w[i >> 2] >> (8 * (i & 3))) & 0xffu] == 2u) << i;
+        const i64 left = nvox - v0;
+        if (left < 16) bits &= (1u << left) - 1u;
+        return bits;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) bits |= (u32)(((w[i >> 2] >> (8 * (i & 3))) & 0xffu) != 0u) << i;
     return bits;
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256) void k_points_count16(const u8* __restrict__ g
     __syncthreads();
     const i64 v0 = (i64)blockIdx.x * kBlockVox + 16 * threadIdx.x;
     u32 w[12];
-    const u32 sel = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
+    const u32 sel = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w, p.labelsel ? htab : nullptr)) : 0u;
     masks[(i64)blockIdx.x * 256 + threadIdx.x] = (unsigned short)sel;
     u32 c = (u32)__popc(sel);
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     }
     u32 w[12];
     u32 bits;
-    if (SINGLE) bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w)) : 0u;
+    if (SINGLE) bits = v0 < p.nlat ? (C == 3 ? select16(p, htab, grid, v0, p.nlat, w) : select16_occ(grid, v0, p.nlat, w, p.labelsel ? htab : nullptr)) : 0u;
     else {
         // the count pass left the selection: only the voxels' bytes (their colours) are needed, and only where something is selected
         bits = masks[(i64)bid * 256 + threadIdx.x];
@@ -508,7 +521,7 @@ int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, in
                  (long long)A0, (long long)A1, (long long)A2, C);
     PB3D_REQUIRE(stride >= 1, "pb3d_points: stride must be >= 1");
     PB3D_REQUIRE(ncolors >= 0 && ncolors <= 32, "pb3d_points: at most 32 colours");
-    PB3D_REQUIRE(ncolors == 0 || (C == 3 && colors), "pb3d_points: colour selection needs an RGB grid");
+    PB3D_REQUIRE(ncolors == 0 || colors, "pb3d_points: null colour set");      // C == 1: `colors` holds ncolors 1-byte LABELS
     p->A1 = A1; p->A2 = A2;
     p->packed = (stride == 1 && A0 < (1 << 21) && A1 < (1 << 21) && A2 < (1 << 21) && A2 >= 64 && A0 * A1 * A2 <= 0xffffffffll) ? 1 : 0;
     const i64 L0 = (A0 + stride - 1) / stride;
@@ -516,6 +529,18 @@ int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, in
     p->nlat = L0 * p->L1 * p->L2;
     p->C = C; p->ncolors = ncolors; p->stride = stride;
     memset(p->colors, 0, sizeof(p->colors));
+    p->labelsel = (C == 1 && ncolors > 0) ? 1 : 0;
+    if (p->labelsel) {
+        memcpy(p->colors, colors, (size_t)ncolors);
+        for (int k = 0; k < 32; ++k) p->colors32[k] = 0xffffffffu;
+        p->hashK = 0;
+        for (int e = 0; e < 256; ++e) p->htab[e] = 1u;
+        for (int k = 0; k < ncolors; ++k) p->htab[colors[k]] = 2u;
+        const Magic h2 = make_magic((u32)(A2 > 0 ? A2 : 1)), h1 = make_magic((u32)(A1 > 0 ? A1 : 1));
+        p->m2 = h2.m; p->s2a = h2.sa; p->s2b = h2.sb;
+        p->m1 = h1.m; p->s1a = h1.sa; p->s1b = h1.sb;
+        return PB3D_OK;
+    }
     if (ncolors) memcpy(p->colors, colors, (size_t)3 * ncolors);
     for (int k = 0; k < 32; ++k)
         p->colors32[k] = k < ncolors ? ((u32)colors[3 * k] | ((u32)colors[3 * k + 1] << 8) | ((u32)colors[3 * k + 2] << 16)) : 0xffffffffu;
@@ -563,7 +588,7 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
     void *counts, *offsets;
     PB3D_TRY(pb3d_scratch(ctx, 8, (size_t)nb * sizeof(u32), &counts));
     PB3D_TRY(pb3d_scratch(ctx, 9, (size_t)(nb + 1) * sizeof(i64), &offsets));
-    const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
+    const bool fast16 = stride == 1 && (((uintptr_t)d_grid) & 15u) == 0;
     void* masks = nullptr;
     if (fast16) PB3D_TRY(pb3d_scratch(ctx, 25, (size_t)nb * 256 * sizeof(unsigned short), &masks));
     if (fast16 && C == 3) hipLaunchKernelGGL(k_points_count16<3>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (u32*)counts, (unsigned short*)masks);
@@ -604,7 +629,7 @@ int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64
     const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
     PB3D_REQUIRE(ctx->scratch[9] && ctx->scratch_bytes[9] >= (size_t)(nb + 1) * sizeof(i64),
                  "pb3d_points_fill: call pb3d_points_count first");
-    const bool fast16 = stride == 1 && (C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0;
+    const bool fast16 = stride == 1 && (((uintptr_t)d_grid) & 15u) == 0;
     PB3D_REQUIRE(!fast16 || (ctx->scratch[25] && ctx->scratch_bytes[25] >= (size_t)nb * 256 * sizeof(unsigned short)),
                  "pb3d_points_fill: call pb3d_points_count first");
     if (fast16 && C == 1)
@@ -629,7 +654,7 @@ int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, in
     PB3D_TRY(make_params(A0, A1, A2, C, colors, ncolors, 1, &p));
     if (p.nlat == 0) return PB3D_OK;
     PB3D_REQUIRE(d_grid && (capacity == 0 || (d_pts && d_cols)), "pb3d_points_extract: null buffer");
-    PB3D_REQUIRE((C == 3 || ncolors == 0) && (((uintptr_t)d_grid) & 15u) == 0, "pb3d_points_extract: needs a 16-byte aligned grid (C == 3, or C == 1 without a colour set)");
+    PB3D_REQUIRE((((uintptr_t)d_grid) & 15u) == 0, "pb3d_points_extract: needs a 16-byte aligned grid");
     const i64 nb = (p.nlat + kBlockVox - 1) / kBlockVox;
     PB3D_REQUIRE(nb < (1ll << 31), "pb3d_points_extract: grid too large");
     void* stv;

@@ -5,10 +5,14 @@ utils.projection_utils, utils.camera_geometry, utils.camera_estimation.compute_p
 utils.config) on top of libpb3d.so.  `install()` rebinds those names inside an imported
 reference `utils` package so notebooks 1-3 run unchanged.
 """
-from . import _hostmem, _lib, device, dist, labels  # noqa: F401
-from .labels import Palette, global_carve_labels, label_to_rgb, part_carve_labels, rgb_to_label  # noqa: F401
+from . import _hostmem, _lib, device, dist, formats, labels  # noqa: F401
+from .formats import load_camera_params, load_voxel_grid, save_camera_params, save_voxel_grid  # noqa: F401
+from .labels import (Palette, extrude_from_surface_labels, get_voxel_points_by_parts_labels, global_carve_labels, label_to_rgb,  # noqa: F401
+                     left_right_guided_carve_labels, part_carve_labels, partwise_carve_labels, recolor_backward_components_labels, rgb_to_label,
+                     voxel_grid_to_points_labels)
 from ._hostmem import set_result_pool  # noqa: F401
-from .camera_estimation import CameraObjective, compute_partwise_iou, projection_iou_by_part  # noqa: F401
+from .camera_estimation import (CameraObjective, compute_partwise_iou, coordinate_descent, powell_search, projection_iou_by_part,  # noqa: F401
+                                random_search)
 from .eval_helpers_intra import compute_global_depth_buffer, project_part_visible  # noqa: F401
 from .mask_utils import load_and_prepare_masks, load_mask, mask_parts_from_image  # noqa: F401
 from .camera_geometry import look_at_rotation, project  # noqa: F401

@@ -82,6 +82,11 @@ _SIGNATURES = {
     "pb3d_crop_occupancy_dev": [vp, vp, i64, i64, i64, i64p, i64p, vp],
     "pb3d_component_paste_dev": [vp, vp, vp, C.c_int32, vp, i64, i64, i64, i64p, i64p, vp],
     "pb3d_guided_carve_dev": [vp, vp, vp, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, i64p, intp],
+    "pb3d_guided_carve_label_dev": [vp, vp, vp, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, i64p, intp],
+    "pb3d_label_value_stats_dev": [vp, vp, i64, i64, i64, C.c_uint8, vp, i64p, i64, i64p, i64p, i64p, intp],
+    "pb3d_extrude_label_dev": [vp, vp, i64, i64, i64, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp],
+    "pb3d_recolor_components_label_dev": [vp, vp, i64, u8p, i64, C.c_uint8, vp],
+    "pb3d_orient_label_dev": [vp, vp, i64, i64, i64, vp],
     "pb3d_count_nonzero_dev": [vp, vp, i64, vp],
     "pb3d_recolor_components_dev": [vp, vp, i64, u8p, i64, u8p, vp],
     "pb3d_extrude_dev": [vp, vp, i64, i64, i64, vp, i64, C.c_int, C.c_int, C.c_int, u8p, vp],

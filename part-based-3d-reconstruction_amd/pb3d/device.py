@@ -74,6 +74,16 @@ class DeviceGrid:
     def free(self):
         self.buf.free()
 
+    def save_npz(self, path):
+        """the stage hand-off file of the notebooks (np.savez_compressed with the single key `voxel_grid`); pb3d/formats.py"""
+        from .formats import save_voxel_grid
+        save_voxel_grid(path, self)
+
+    @classmethod
+    def load_npz(cls, path):
+        from .formats import load_voxel_grid
+        return load_voxel_grid(path, on_device=True)
+
 
 def from_numpy(array):
     a = np.ascontiguousarray(array)

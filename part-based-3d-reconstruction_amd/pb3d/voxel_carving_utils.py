@@ -318,9 +318,14 @@ def _label_stats(d_grid, shape3, color_u8, d_labels, cap=1024):
     A0, A1, A2 = shape3
     n = C.c_int64(0); ok = C.c_int(0)
     bbox = np.zeros((cap, 6), np.int64); cnt = np.zeros(cap, np.int64); sums = np.zeros((cap, 3), np.int64)
-    _lib.check(_lib.load().pb3d_label_color_stats_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, _lib.p_u8(color_u8), C.c_void_p(d_labels.ptr),
-                                                      C.byref(n), cap, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
-                                                      sums.ctypes.data_as(_lib.i64p), C.byref(ok)))
+    if isinstance(color_u8, (int, np.integer)):          # a 1-byte label volume (pb3d.labels): components of one label value
+        _lib.check(_lib.load().pb3d_label_value_stats_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, int(color_u8), C.c_void_p(d_labels.ptr),
+                                                          C.byref(n), cap, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
+                                                          sums.ctypes.data_as(_lib.i64p), C.byref(ok)))
+    else:
+        _lib.check(_lib.load().pb3d_label_color_stats_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, _lib.p_u8(color_u8), C.c_void_p(d_labels.ptr),
+                                                          C.byref(n), cap, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
+                                                          sums.ctypes.data_as(_lib.i64p), C.byref(ok)))
     if not ok.value:
         return (n.value,) + _component_stats(d_labels, shape3, n.value)
     return n.value, bbox[:n.value], cnt[:n.value], sums[:n.value]
@@ -333,18 +338,18 @@ def _check_angle_step(angle):
         raise ValueError("range() arg 3 must not be zero")
 
 
-def _lrgc_dev(d_col, shape3, mask2d, target_color, angle):
+def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
     """left_right_guided_carve on a device-resident grid.  Returns the DeviceBuffer that holds the result: d_col itself when the
     fused component loop ran (csrc/guided.hip: in place, one launch pair per batch of components), else a new buffer."""
     from . import device as dev
     W, H, D = shape3
     lib, ctx = _lib.load(), _lib.ctx()
-    nbytes = W * H * D * 3
+    nbytes = W * H * D * (3 if label is None else 1)      # label: d_col is a 1-byte label volume and `label` the part's label value
     d_lab = dev.DeviceBuffer(W * H * D * 4)
     d_carved = None
     tmp = []
     try:
-        cu8 = _color_u8(target_color)
+        cu8 = _color_u8(target_color) if label is None else int(label)
         num, bbox, _, _ = _label_stats(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else (0, None, None, None)
         print(f"[{target_color}] 3D components: {num}")
         if not num:
@@ -364,11 +369,14 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle):
         if angle > 0:
             bb = np.ascontiguousarray(bbox, np.int64); mo = np.asarray(offs, np.int64); cn = np.zeros(num, np.int64)
             took = C.c_int(0)
-            _lib.check(lib.pb3d_guided_carve_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), W, H, D, num, bb.ctypes.data_as(_lib.i64p),
+            fn = lib.pb3d_guided_carve_dev if label is None else lib.pb3d_guided_carve_label_dev
+            _lib.check(fn(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), W, H, D, num, bb.ctypes.data_as(_lib.i64p),
                                                  _lib.p_u8(packed), mo.ctypes.data_as(_lib.i64p), packed.size, int(min(angle, 91)),
                                                  cn.ctypes.data_as(_lib.i64p), C.byref(took)))
             if took.value:
                 counts = cn
+        if counts is None and label is not None:
+            raise ValueError("left_right_guided_carve on labels: a component's 32-plane slice does not fit the LDS (or angle < 0); use the RGB form")
         if counts is None:
             # a crop too large for the LDS-resident chain (or an empty angle loop): component by component, into a copy
             d_carved = dev.DeviceBuffer(nbytes)
@@ -451,14 +459,19 @@ def _extrude_args(shape3, mask_2d, axis, direction):
     return _lib.truth_u8(valid), vw
 
 
-def _extrude_dev(d_in, d_out, shape3, valid_u8, vw, axis, direction, depth, fill_color, d_valid=None):
+def _extrude_dev(d_in, d_out, shape3, valid_u8, vw, axis, direction, depth, fill_color, d_valid=None, label=False):
     """one extrusion on device buffers; d_out may be d_in (in place).  d_valid: the mask already on the device (a chain of calls
     with one mask uploads it once); the call only queues work."""
     from . import device as dev
     W, H, D = shape3
-    fc = None if fill_color is None else np.ascontiguousarray(np.asarray(fill_color).astype(np.uint8).reshape(3))
+    fc = None if (fill_color is None or label) else np.ascontiguousarray(np.asarray(fill_color).astype(np.uint8).reshape(3))
     d_v = d_valid if d_valid is not None else dev.from_numpy(valid_u8)
     try:
+        if label:       # 1-byte label volume: fill_color is the label value (None clears)
+            _lib.check(_lib.load().pb3d_extrude_label_dev(_lib.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_v.ptr), vw, int(axis),
+                                                          1 if direction == "+" else 0, int(depth), -1 if fill_color is None else int(fill_color),
+                                                          C.c_void_p(d_out.ptr)))
+            return
         _lib.check(_lib.load().pb3d_extrude_dev(_lib.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_v.ptr), vw, int(axis),
                                                 1 if direction == "+" else 0, int(depth), None if fc is None else _lib.p_u8(fc),
                                                 C.c_void_p(d_out.ptr)))
@@ -486,11 +499,11 @@ def extrude_from_surface(grid, mask_2d, axis, direction="+", depth=5, fill_color
         d_in.free(); d_out.free()
 
 
-def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis):
+def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis, label=False):
     """recolor_backward_components in place on a device-resident (A0,A1,A2,3) grid."""
     from . import device as dev
     A0, A1, A2 = shape3
-    cu8 = _color_u8(color)
+    cu8 = int(color) if label else _color_u8(color)
     if cu8 is None or A0 * A1 * A2 == 0:
         return
     d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
@@ -501,6 +514,11 @@ def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis):
         means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column
         keep = {i for i, _ in sorted(means, key=lambda t: t[1])[:k]}
         flags = np.array([0 if (i + 1) in keep else 1 for i in range(n)], np.uint8)
+        if label:
+            _lib.check(_lib.load().pb3d_recolor_components_label_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n, int(new_color),
+                                                                     C.c_void_p(d_g.ptr)))
+            dev.sync()
+            return
         nc = np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
         _lib.check(_lib.load().pb3d_recolor_components_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n,
                                                            _lib.p_u8(nc), C.c_void_p(d_g.ptr)))

@@ -121,9 +121,8 @@ def test_points_golden(pb3d_gpu, golden):
 
 
 def _cams(mon):
-    cams = json.load(open(os.path.join(GOLDEN, f"stored_{mon}_camera_params_final.json")))
-    conv = lambda o: np.array(o, np.float32) if isinstance(o, list) else ({k: conv(v) for k, v in o.items()} if isinstance(o, dict) else o)
-    return conv(cams)
+    from pb3d.formats import load_camera_params          # the notebook-3 to_numpy rule (cell 3)
+    return load_camera_params(os.path.join(GOLDEN, f"stored_{mon}_camera_params_final.json"))
 
 
 @pytest.mark.parametrize("mon", ["Akbar", "Charminar"])
@@ -1362,3 +1361,70 @@ def test_search_loops_batched_equal_the_reference_buttons(pb3d_gpu):
         assert s1 == case["after_random"], (parts, "random")
         assert s2 == case["after_coord"], (parts, "coord")
         assert s3 == case["after_powell"], (parts, "powell")
+
+
+def test_orient_kernels(pb3d_gpu):
+    """the output orientation of partwise_carve (reference utils/voxel_carving_utils.py:384-385: flip(transpose(2,1,0,3), axis=1)) as
+    ONE pass: the 128-pixel-tile kernel (x and z extents multiples of 128: whole 128-byte lines on both sides), the dword kernel
+    (multiples of 4) and the byte kernel, against NumPy."""
+    import ctypes as C
+    from pb3d import device as dev
+    L = pb3d_gpu._lib
+    rng = np.random.default_rng(12)
+    for (W, H, D) in [(128, 5, 128), (256, 3, 128), (128, 4, 384), (64, 3, 64), (37, 5, 41), (128, 2, 100), (132, 3, 128)]:
+        g = rng.integers(0, 256, (W, H, D, 3), dtype=np.uint8)
+        want = np.ascontiguousarray(np.flip(g.transpose(2, 1, 0, 3), axis=1))
+        d_in = dev.from_numpy(g); d_out = dev.DeviceBuffer(g.size)
+        for knob in (0, 5):                      # 5: without the 128-tile kernel
+            L.set_tuning("misc2", knob)
+            try:
+                L.check(L.load().pb3d_orient_dev(L.ctx(), C.c_void_p(d_in.ptr), W, H, D, C.c_void_p(d_out.ptr)))
+                got = d_out.download((D, H, W, 3))
+            finally:
+                L.set_tuning("misc2", 0)
+            assert np.array_equal(got, want), (W, H, D, knob)
+        d_in.free(); d_out.free()
+
+
+@pytest.mark.parametrize("name", ["Taj_96", "Akbar_64"])
+def test_label_chain_end_to_end(pb3d_gpu, golden, name):
+    """Row N3: the WHOLE notebook-1 chain on 1-byte label volumes (global_carve -> part_carve -> component-guided carve -> extrusion
+    -> orientation -> recolouring) expands to the reference's partwise_carve digest; its stages equal the RGB stages and print the
+    RGB log; point extraction on label volumes (by parts, by occupancy with a stride) equals the RGB extraction of the expanded grid."""
+    import contextlib
+    import io
+    g = golden(f"f5_{name}")
+    meta = json.load(open(os.path.join(GOLDEN, "f5_meta.json")))[name]
+    PC = pb3d_gpu.PART_COLORS; PCN = pb3d_gpu.PART_COLORS_NP
+    pal = pb3d_gpu.Palette.from_part_colors(PC)
+    lab_ext = pal.mask_to_labels(g["ext"]); lab_sem = pal.mask_to_labels(g["sem"])
+    lgc = pb3d_gpu.global_carve_labels(g["binary"], lab_ext)
+    lpc = pb3d_gpu.part_carve_labels(lgc, lab_ext, JOBS_NB1, pal)
+    grid = lpc
+    for (part, angle), want_log in zip(PART_SYMMETRY.items(), meta["lrgc_stdout"]):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            grid = pb3d_gpu.left_right_guided_carve_labels(grid, lab_ext, pal.label_of(part), angle=angle, log_color=PCN[part])
+        assert sha(pb3d_gpu.label_to_rgb(grid, pal)) == meta["stages"][f"lrgc_{part}"], part
+        assert buf.getvalue() == want_log
+    for part, depth in EXTRUSION.items():
+        mk = lab_sem == pal.label_of(part)
+        for ax, dr in ((2, "+"), (2, "-"), (0, "+"), (0, "-")):
+            grid = pb3d_gpu.extrude_from_surface_labels(grid, mk, axis=ax, direction=dr, depth=depth, fill_label=pal.label_of(part))
+            assert sha(pb3d_gpu.label_to_rgb(grid, pal)) == meta["stages"][f"extrude_{part}_{ax}{dr}"], (part, ax, dr)
+    oriented = np.flip(grid.transpose(2, 1, 0), axis=1)
+    rec = pb3d_gpu.recolor_backward_components_labels(oriented, pal.label_of("front_minarets"), pal.label_of("back_minarets"), k=2, sort_axis=0)
+    assert np.array_equal(pb3d_gpu.label_to_rgb(rec, pal), g["after_recolor"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = pb3d_gpu.partwise_carve_labels(lgc, lab_ext, lab_sem, pal, JOBS_NB1, PART_SYMMETRY, EXTRUSION)
+    rgb = pb3d_gpu.label_to_rgb(full, pal)
+    assert sha(rgb) == meta["partwise_sha256"] and list(rgb.shape) == meta["partwise_shape"]
+    # point extraction on the label volume == on the expanded grid
+    for parts in (["dome", "plinth"], ["front_minarets"], list(PC.keys())):
+        p1, c1 = pb3d_gpu.get_voxel_points_by_parts_labels(full, pal, parts)
+        p2, c2 = pb3d_gpu.get_voxel_points_by_parts(rgb, PC, parts)
+        assert np.array_equal(p1, p2) and np.array_equal(c1, c2), parts
+    for st in (1, 2, 3):
+        p1, c1, s1 = pb3d_gpu.voxel_grid_to_points_labels(full, pal, stride=st)
+        p2, c2, s2 = pb3d_gpu.voxel_grid_to_points(rgb, stride=st)
+        assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and tuple(s1) == tuple(s2)[:3], st

@@ -185,3 +185,29 @@ def test_search_loop_drivers_reproduce_the_reference_buttons(oracle):
         assert s1 == case["after_random"], (case["parts"], "random")
         assert s2 == case["after_coord"], (case["parts"], "coord")
         assert s3 == case["after_powell"], (case["parts"], "powell")
+
+
+def test_handoff_formats_roundtrip(tmp_path):
+    """Row N3, the files either side of the path: a grid saved like notebook 1 cell 9 is what notebook 2 cell 3 loads (key
+    `voxel_grid`, stored (D,H,W,3) layout: the reference's own results/1 file loads through the package), camera parameters go out as
+    notebook 2 cell 11 writes them and come back by notebook 3's to_numpy rule (lists -> float32 arrays, scalars stay Python floats)."""
+    import json
+    from pb3d import formats
+    stored = os.path.join(os.path.dirname(__file__), "golden", "stored_Akbar_voxel_grid.npz")
+    g = formats.load_voxel_grid(stored)
+    assert g.dtype == np.uint8 and g.ndim == 4 and g.shape[3] == 3
+    p = str(tmp_path / "Akbar_voxel_grid.npz")
+    formats.save_voxel_grid(p, g)
+    with np.load(p) as f:
+        assert list(f.keys()) == ["voxel_grid"] and np.array_equal(f["voxel_grid"], g)
+    cams = {"front": {"cam_pos": np.array([1.5, 2.0, -300.25]), "target": np.array([64.0, 60.0, 64.0], np.float32), "f": 450.5, "cx": 64.0, "cy": np.float64(61.5),
+                      "H": 123, "W": 128}}
+    q = str(tmp_path / "Akbar_camera_params_final.json")
+    formats.save_camera_params(q, cams)
+    raw = json.load(open(q))
+    assert raw["front"]["cam_pos"] == [1.5, 2.0, -300.25] and raw["front"]["cy"] == 61.5
+    back = formats.load_camera_params(q)
+    assert back["front"]["cam_pos"].dtype == np.float32 and isinstance(back["front"]["f"], float) and isinstance(back["front"]["H"], int)
+    assert np.array_equal(back["front"]["target"], cams["front"]["target"])
+    ref = formats.load_camera_params(os.path.join(os.path.dirname(__file__), "golden", "stored_Akbar_camera_params_final.json"))
+    assert ref["front"]["cam_pos"].dtype == np.float32 and ref["front"]["cam_pos"].shape == (3,)
