@@ -338,7 +338,8 @@ def voxel_grid_to_points_labels(label_grid, palette, stride=2):
     pal = _pal(palette)
     g = _lib.as_u8(label_grid, "label_grid")
     pts, cols = _points_labels_occ(g, stride, pal)
-    return pts, cols, g.shape
+    W, H, D = g.shape
+    return pts, cols, (H, W, D)          # (upstream unpacks W, H, D = shape[:3] and returns them in this order, :37 / :51)
 
 
 def _points_labels_occ(g, stride, pal):

@@ -1427,4 +1427,4 @@ def test_label_chain_end_to_end(pb3d_gpu, golden, name):
     for st in (1, 2, 3):
         p1, c1, s1 = pb3d_gpu.voxel_grid_to_points_labels(full, pal, stride=st)
         p2, c2, s2 = pb3d_gpu.voxel_grid_to_points(rgb, stride=st)
-        assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and tuple(s1) == tuple(s2)[:3], st
+        assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and tuple(s1) == tuple(s2), st
