@@ -356,9 +356,9 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits
                             atomicAdd(&scs[found][0], cnt);
                             for (int a = 0; a < 3; ++a) atomicAdd(&scs[found][1 + a], sm[a]);
                         } else {
-                            int* bb = bbox + 6 * (L - 1);
+                            int* bb = bbox + 16 * (L - 1);                          // one 64-byte record per component: 6 ints of box, 4 u64 of count / sums
                             for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], lo[a]); atomicMax(&bb[3 + a], hi[a]); }
-                            unsigned long long* cs = cnt_sum + 4 * (L - 1);
+                            unsigned long long* cs = cnt_sum + 8 * (L - 1);
                             atomicAdd(&cs[0], cnt);
                             for (int a = 0; a < 3; ++a) atomicAdd(&cs[1 + a], sm[a]);
                         }
@@ -374,18 +374,20 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits
         __syncthreads();
         if (threadIdx.x < kFinSlots && slab[threadIdx.x] > 0) {
             const int Lc = slab[threadIdx.x];
-            int* bb = bbox + 6 * (Lc - 1);
+            int* bb = bbox + 16 * (Lc - 1);
             for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], slo[threadIdx.x][a]); atomicMax(&bb[3 + a], shi[threadIdx.x][a]); }
-            unsigned long long* cs = cnt_sum + 4 * (Lc - 1);
+            unsigned long long* cs = cnt_sum + 8 * (Lc - 1);
             for (int a = 0; a < 4; ++a) atomicAdd(&cs[a], scs[threadIdx.x][a]);
         }
     }
 }
 
+// the statistics block: a 64-byte header (the component count lands here) + one 64-byte record per component
+// {int lo[3], hi[3], pad[2]; u64 count, sum[3]} -- the count and the first records come back in ONE copy
 __global__ __launch_bounds__(256) void k_fin_stats_init(int cap, int* __restrict__ bbox, unsigned long long* __restrict__ cnt_sum) {
     for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < cap; k += (int)(gridDim.x * blockDim.x)) {
-        for (int a = 0; a < 3; ++a) { bbox[6 * k + a] = 0x7fffffff; bbox[6 * k + 3 + a] = -1; }
-        for (int a = 0; a < 4; ++a) cnt_sum[4 * k + a] = 0ull;
+        for (int a = 0; a < 3; ++a) { bbox[16 * k + a] = 0x7fffffff; bbox[16 * k + 3 + a] = -1; }
+        for (int a = 0; a < 4; ++a) cnt_sum[8 * k + a] = 0ull;
     }
 }
 
@@ -410,14 +412,13 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nwords * 8, &rootbits));
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nchunks * 8 + 16, &chunks));
     const int dcap = stats ? (int)(cap < 16384 ? cap : 16384) : 0;
-    void *sbb = nullptr, *scs = nullptr;
-    if (stats) {
-        PB3D_TRY(pb3d_scratch(ctx, 40, (size_t)16384 * 6 * sizeof(int), &sbb));
-        PB3D_TRY(pb3d_scratch(ctx, 41, (size_t)16384 * 4 * sizeof(unsigned long long), &scs));
-    }
+    void *sblk = nullptr, *sbb = nullptr, *scs = nullptr;
+    PB3D_TRY(pb3d_scratch(ctx, 40, 64 + (size_t)16384 * 64, &sblk));
+    sbb = (char*)sblk + 64;                 // int view of record k: sbb + 16 k ints
+    scs = (char*)sblk + 64 + 32;            // u64 view of record k: scs + 8 k u64 (the second half of the record)
     u32* chunk_count = (u32*)chunks;
     u32* chunk_base = chunk_count + nchunks;
-    i64* total = (i64*)((char*)chunks + (((size_t)nchunks * 8 + 7) & ~(size_t)7));
+    i64* total = (i64*)sblk;                // (the header of the statistics block)
     const u32 color24 = C == 1 ? (u32)color[0] : ((u32)color[0] | ((u32)color[1] << 8) | ((u32)color[2] << 16));
     const pb3d_magic mP = pb3d_make_magic((u32)P), m1 = pb3d_make_magic((u32)A1);
     int* parent = (int*)d_labels;
@@ -450,17 +451,15 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
                            parent, m1, 0, (int*)nullptr, (unsigned long long*)nullptr);
     }
     PB3D_CHECK_LAUNCH();
-    // the component count and -- optimistically -- the statistics of the first kFirst components come back in ONE round trip
+    // the component count and -- optimistically -- the statistics of the first kFirst components come back in ONE copy, one round trip
     constexpr int kFirst = 64;
-    struct Back { i64 nroots; int bb[kFirst * 6]; unsigned long long cs[kFirst * 4]; };
+    struct Rec { int bb[8]; unsigned long long cs[4]; };
+    struct Back { i64 nroots; i64 pad[7]; Rec rec[kFirst]; };
+    static_assert(sizeof(Rec) == 64 && sizeof(Back) == 64 + 64 * kFirst, "the statistics block is 64-byte records");
     Back* hb = (Back*)((char*)ctx->pinned + 1024);
     static_assert(sizeof(Back) + 1024 + 64 <= (1 << 16), "the pinned area holds the read-back block");
-    PB3D_HIP(hipMemcpyAsync(&hb->nroots, total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     const int nf = dcap < kFirst ? dcap : kFirst;
-    if (stats && nf > 0) {
-        PB3D_HIP(hipMemcpyAsync(hb->bb, sbb, (size_t)nf * 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PB3D_HIP(hipMemcpyAsync(hb->cs, scs, (size_t)nf * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    PB3D_HIP(hipMemcpyAsync(hb, sblk, 64 + (size_t)(stats ? nf : 0) * 64, hipMemcpyDeviceToHost, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));
     const i64 nroots = hb->nroots;
     *ncomp = nroots;
@@ -471,14 +470,12 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
             for (int a = 0; a < 3; ++a) coord_sum[3 * k + a] = (i64)c4[1 + a];
         };
         const i64 n0 = nroots < nf ? nroots : nf;
-        for (i64 k = 0; k < n0; ++k) put(k, hb->bb + 6 * k, hb->cs + 4 * k);
+        for (i64 k = 0; k < n0; ++k) put(k, hb->rec[k].bb, hb->rec[k].cs);
         if (nroots > n0) {
-            std::vector<int> hbb((size_t)(nroots - n0) * 6);
-            std::vector<unsigned long long> hcs((size_t)(nroots - n0) * 4);
-            PB3D_HIP(hipMemcpyAsync(hbb.data(), (const int*)sbb + 6 * n0, hbb.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            PB3D_HIP(hipMemcpyAsync(hcs.data(), (const unsigned long long*)scs + 4 * n0, hcs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            std::vector<Rec> more((size_t)(nroots - n0));
+            PB3D_HIP(hipMemcpyAsync(more.data(), (const char*)sblk + 64 + 64 * n0, more.size() * sizeof(Rec), hipMemcpyDeviceToHost, ctx->stream));
             PB3D_HIP(hipStreamSynchronize(ctx->stream));
-            for (i64 k = n0; k < nroots; ++k) put(k, hbb.data() + 6 * (k - n0), hcs.data() + 4 * (k - n0));
+            for (i64 k = n0; k < nroots; ++k) put(k, more[(size_t)(k - n0)].bb, more[(size_t)(k - n0)].cs);
         }
         *stats_valid = 1;
     }

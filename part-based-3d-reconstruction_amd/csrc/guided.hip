@@ -231,12 +231,12 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
             par_bytes = std::max(par_bytes, n * (size_t)(nrot > 0 ? nrot : 1) * sizeof(RotParams));
             tab_bytes = std::max(tab_bytes, cells * (size_t)(nrot > 0 ? nrot : 1) * sizeof(u32));
         }
-        void *dd, *dp, *dt;
-        // one region per batch would let the batches overlap; they are in stream order anyway, but the UPLOAD of batch b + 1 must not
-        // overwrite what batch b's kernels still read: every batch gets its own slice of the slots
+        void *dd, *dt;
+        // every batch gets its own slice of the slot ([descriptors | step parameters], ONE upload): the upload of batch b + 1 must not
+        // overwrite what batch b's kernels still read
         const size_t nb = batches.size();
-        PB3D_TRY(pb3d_scratch(ctx, 36, desc_bytes * nb, &dd));
-        PB3D_TRY(pb3d_scratch(ctx, 33, par_bytes * nb, &dp));
+        const size_t slice = ((desc_bytes + par_bytes) + 63) & ~(size_t)63;
+        PB3D_TRY(pb3d_scratch(ctx, 36, slice * nb, &dd));
         PB3D_TRY(pb3d_scratch(ctx, 38, tab_bytes, &dt));
         for (size_t bi = 0; bi < nb; ++bi) {
             const i64 a = batches[bi].first, e = batches[bi].second;
@@ -266,12 +266,14 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
                     ps.push_back(RotParams{M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]});
                 }
             }
-            CropDesc* ddb = (CropDesc*)((char*)dd + desc_bytes * bi);
-            RotParams* dpb = (RotParams*)((char*)dp + par_bytes * bi);
+            static_assert(sizeof(CropDesc) == sizeof(RotParams), "descriptors and parameters share one staging vector");
+            const size_t nd = ds.size();
+            for (const RotParams& rp : ps) { CropDesc as; memcpy(&as, &rp, sizeof(as)); ds.push_back(as); }     // [descriptors | parameters]
+            CropDesc* ddb = (CropDesc*)((char*)dd + slice * bi);
+            RotParams* dpb = (RotParams*)(ddb + nd);
             PB3D_HIP(hipMemcpyAsync(ddb, ds.data(), ds.size() * sizeof(CropDesc), hipMemcpyHostToDevice, ctx->stream));
             const int n = (int)(e - a);
             if (nrot > 0) {
-                PB3D_HIP(hipMemcpyAsync(dpb, ps.data(), ps.size() * sizeof(RotParams), hipMemcpyHostToDevice, ctx->stream));
                 dim3 gridc((unsigned)std::min((maxcells + 255) / 256, 64), (unsigned)(n * nrot));
                 PB3D_REQUIRE(gridc.y <= 65535u, "pb3d_guided_carve: too many (component, step) pairs in a batch");
                 hipLaunchKernelGGL(k_crop_cells, gridc, dim3(256), 0, ctx->stream, (const CropDesc*)ddb, (const RotParams*)dpb, nrot, (u32*)dt);
