@@ -286,7 +286,7 @@ constexpr int kFinSlots = 16;
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits, i64 rows, int A2, int P, int* parent, pb3d_magic m1, int cap,
-                                                    int* __restrict__ bbox, unsigned long long* __restrict__ cnt_sum) {
+                                                    int* __restrict__ bbox, unsigned long long* __restrict__ cnt_sum, int abl) {
     __shared__ int table[4][kChunkWin][32];                      // labels of the runs that start in window t, in order
     __shared__ int slab[kFinSlots];
     __shared__ int slo[kFinSlots][3], shi[kFinSlots][3];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits
                 if ((w >> lane) & 1ull) st(&parent[base + 64u * (u32)(t0 + tt) + (u32)lane], L);
                 if (STATS) {
                     const bool seg = ((w >> lane) & 1ull) && (lane == 0 || !((w >> (lane - 1)) & 1ull));
-                    if (seg && L > 0 && L <= cap) {
+                    if (seg && L > 0 && L <= cap && !(abl & 2)) {
                         const u64 stop = ~w & ~le;                                   // the first non-member above this lane
                         const int len = (stop ? __ffsll((unsigned long long)stop) - 1 : 64) - lane;
                         const u32 a0 = pb3d_div(row, m1), a1 = row - a0 * m1.d;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits
     }
     if (STATS) {
         __syncthreads();
-        if (threadIdx.x < kFinSlots && slab[threadIdx.x] > 0) {
+        if (threadIdx.x < kFinSlots && slab[threadIdx.x] > 0 && !(abl & 1)) {
             const int Lc = slab[threadIdx.x];
             int* bb = bbox + 16 * (Lc - 1);
             // thousands of blocks flush into the same few records and same-address atomics serialise: a box that is already wide
@@ -393,6 +393,80 @@ __global__ __launch_bounds__(256) void k_fin_stats_init(int cap, int* __restrict
     for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < cap; k += (int)(gridDim.x * blockDim.x)) {
         for (int a = 0; a < 3; ++a) { bbox[16 * k + a] = 0x7fffffff; bbox[16 * k + 3 + a] = -1; }
         for (int a = 0; a < 4; ++a) cnt_sum[8 * k + a] = 0ull;
+    }
+}
+
+}  // namespace
+
+namespace {
+// The per-component statistics (bounding box, voxel count, coordinate sums) from the membership bits + the finished labels, queued
+// right behind the labelling (one host round trip for both).  Only windows that hold members are looked at -- the separate pass of
+// pb3d_component_stats_dev re-reads the whole 4 B/voxel label volume -- and the launch is a FEW persistent blocks: every block ends
+// with a flush of its LDS table into the component records, and same-address global atomics serialise across the chip (gathering
+// the statistics inside k_ccl_finish, one flush per four rows, cost 0.26 ms on the dome and 0.57 ms on the plinth of Taj 512).
+// A wave takes 64 windows at a time (one lane each), then all its lanes work on each non-empty one: a segment of member voxels is one
+// closed-form contribution of its first lane.
+__global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits, const int* __restrict__ labels, i64 nwords, pb3d_magic mP, pb3d_magic m1,
+                                                   int A2, int cap, int* __restrict__ bbox, unsigned long long* __restrict__ cnt_sum) {
+    __shared__ int slab[kFinSlots];
+    __shared__ int slo[kFinSlots][3], shi[kFinSlots][3];
+    __shared__ unsigned long long scs[kFinSlots][4];
+    if (threadIdx.x < kFinSlots) {
+        slab[threadIdx.x] = 0;
+        for (int a = 0; a < 3; ++a) { slo[threadIdx.x][a] = 0x7fffffff; shi[threadIdx.x][a] = -1; }
+        for (int a = 0; a < 4; ++a) scs[threadIdx.x][a] = 0ull;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const u64 le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const i64 nwaves = (i64)gridDim.x * 4, wid = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (i64 c0 = wid * 64; c0 < nwords; c0 += nwaves * 64) {
+        const i64 idx = c0 + lane;
+        const u64 mine = idx < nwords ? bits[idx] : 0ull;
+        u64 todo = __ballot(mine != 0ull);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const u64 w = readlane64(mine, src);
+            const u32 widx = (u32)(c0 + src);
+            const u32 row = pb3d_div(widx, mP), t = widx - row * mP.d;
+            const bool member = (w >> lane) & 1ull;
+            const int L = member ? labels[(i64)row * A2 + 64 * (i64)t + lane] : 0;
+            const bool seg = member && (lane == 0 || !((w >> (lane - 1)) & 1ull));
+            if (!seg || L <= 0 || L > cap) continue;
+            const u64 stop = ~w & ~le;
+            const int len = (stop ? __ffsll((unsigned long long)stop) - 1 : 64) - lane;
+            const u32 a0 = pb3d_div(row, m1), a1 = row - a0 * m1.d;
+            const int a2 = 64 * (int)t + lane;
+            const int lo[3] = {(int)a0, (int)a1, a2}, hi[3] = {(int)a0, (int)a1, a2 + len - 1};
+            const unsigned long long cnt = (unsigned long long)len;
+            const unsigned long long sm[3] = {(unsigned long long)a0 * cnt, (unsigned long long)a1 * cnt, (unsigned long long)(2 * a2 + len - 1) * cnt / 2ull};
+            int slot = L & (kFinSlots - 1), found = -1;
+            for (int k = 0; k < kFinSlots; ++k) {
+                const int old = atomicCAS(&slab[slot], 0, L);
+                if (old == 0 || old == L) { found = slot; break; }
+                slot = (slot + 1) & (kFinSlots - 1);
+            }
+            if (found >= 0) {
+                for (int a = 0; a < 3; ++a) { atomicMin(&slo[found][a], lo[a]); atomicMax(&shi[found][a], hi[a]); }
+                atomicAdd(&scs[found][0], cnt);
+                for (int a = 0; a < 3; ++a) atomicAdd(&scs[found][1 + a], sm[a]);
+            } else {
+                int* bb = bbox + 16 * (L - 1);
+                for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], lo[a]); atomicMax(&bb[3 + a], hi[a]); }
+                unsigned long long* cs = cnt_sum + 8 * (L - 1);
+                atomicAdd(&cs[0], cnt);
+                for (int a = 0; a < 3; ++a) atomicAdd(&cs[1 + a], sm[a]);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kFinSlots && slab[threadIdx.x] > 0) {
+        const int Lc = slab[threadIdx.x];
+        int* bb = bbox + 16 * (Lc - 1);
+        for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], slo[threadIdx.x][a]); atomicMax(&bb[3 + a], shi[threadIdx.x][a]); }
+        unsigned long long* cs = cnt_sum + 8 * (Lc - 1);
+        for (int a = 0; a < 4; ++a) atomicAdd(&cs[a], scs[threadIdx.x][a]);
     }
 }
 
@@ -446,15 +520,13 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     hipLaunchKernelGGL(k_ccl_number, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, nwords, mP, (int)A2, (const u64*)rootbits,
                        (const u32*)chunk_base, parent);
     PB3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ccl_finish<false>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
+                       parent, m1, 0, (int*)nullptr, (unsigned long long*)nullptr, 0);
     if (stats) {
         hipLaunchKernelGGL(k_fin_stats_init, dim3((unsigned)((dcap + 255) / 256)), dim3(256), 0, ctx->stream, dcap, (int*)sbb, (unsigned long long*)scs);
-        // (one block per four rows, like the plain form: only blocks that hold members flush anything; a capped persistent grid made
-        // every block touch every component: 118 -> 150 us at Taj 512)
-        hipLaunchKernelGGL(k_ccl_finish<true>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
-                           parent, m1, dcap, (int*)sbb, (unsigned long long*)scs);
-    } else {
-        hipLaunchKernelGGL(k_ccl_finish<false>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, (const u64*)bits, rows, (int)A2, (int)P,
-                           parent, m1, 0, (int*)nullptr, (unsigned long long*)nullptr);
+        const int sblocks = ctx->tune_misc[0] > 0 ? ctx->tune_misc[0] : 2 * ctx->cus;
+        hipLaunchKernelGGL(k_ccl_stats, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, (const u64*)bits, (const int*)parent, nwords, mP, m1, (int)A2, dcap,
+                           (int*)sbb, (unsigned long long*)scs);
     }
     PB3D_CHECK_LAUNCH();
     // the component count and -- optimistically -- the statistics of the first kFirst components come back in ONE copy, one round trip
