@@ -59,6 +59,7 @@ int pb3d_create(int device, pb3d_ctx** out) {
         ctx->tune_uncap = env_int("PB3D_UNCAP");
         ctx->tune_sliced = env_int("PB3D_SLICED");
         ctx->tune_s32_gpw = env_int("PB3D_S32_GPW");
+        ctx->tune_rot90_wide = env_int("PB3D_ROT90_WIDE");
     }
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
@@ -113,6 +114,8 @@ int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "sliced")) {
         PB3D_REQUIRE(value >= 0 && value <= 2, "pb3d_set_tuning: sliced is 0 (chains), 1 (never) or 2 (single steps too)");
         ctx->tune_sliced = value;
+    } else if (!strcmp(name, "rot90_wide")) {
+        ctx->tune_rot90_wide = value;
     } else if (!strcmp(name, "s32_gpw")) {
         PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: s32_gpw is a count of plane groups");
         ctx->tune_s32_gpw = value;

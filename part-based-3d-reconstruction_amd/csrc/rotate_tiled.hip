@@ -557,6 +557,107 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same step on 256 x 256 tiles (D % 16 == 0, c2 % 16 == 0): rows of 256 bytes -- TWO whole lines -- on BOTH sides from one
+// instruction stream, the access pattern tools/kbench3.hip measured at 0.417 ms against 0.455 ms for 128-byte rows at 1024^3.
+// 1024 threads with k_rot90's roles (staging: 16 lanes per source row, 64 rows per pass, 4 passes; output: 16 z-runs x 64 x-groups
+// of 4 rows), ONE 64 KB tile in LDS (two barriers per plane; the next plane's loads are in flight in registers meanwhile), the
+// 16-byte blocks of a row XOR-swizzled by the row group so that the column reads hit 64 banks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_rot90w(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
+                                                 const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
+                                                 i64 W, i64 H, i64 D, int TY, TileMap tm) {
+    extern __shared__ __attribute__((aligned(16))) u8 wtile[];          // 256 rows x 256 bytes
+    const int tid = threadIdx.x;
+    i64 zt, xt, yc;
+    if (!tile_of_block(tm, &zt, &xt, &yc)) return;
+    const i64 x0 = xt * 256, z0 = zt * 256;
+    const i64 y_beg = yc * TY;
+    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
+    const int cb = tid & 15;                             // staging: 16-byte block of the source row
+    const i64 rbase0 = (i64)c0 - (z0 + 255);            // source row of local row 0
+    const i64 scol = x0 + c2 + 16 * cb;
+    const bool col_ok = scol >= 0 && scol + 15 < D;
+    const int zg = tid & 15, xg = tid >> 4;              // output: z-run (16 z), x-group (4 x)
+    const int g = 15 - zg;                               // row group holding this thread's 16 source rows
+    const u32 rd_off = (u32)(16 * g * 256 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
+    const i64 zo = z0 + 16 * zg;
+    u32 vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 x = x0 + 4 * xg + i;
+        u32 v = 0;
+        if (x < W && zo < D) { const u32* vr = vbits + x * nw + (zo >> 5); v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zo & 31)) & 0xffffu; }
+        vb[i] = v;
+    }
+    u32x4 stg[4];
+    u32 msk;
+    auto load_plane = [&](i64 y) {
+        u32 mk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i64 n0 = rbase0 + (tid >> 4) + 64 * j;
+            stg[j] = (u32x4)(0u);
+            if (y < y_end && col_ok && n0 >= 0 && n0 < W) {
+                stg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
+                mk |= (u32)((mask_src ? mask_src[n0 * H + y] : (u8)1) != 0) << j;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
+        }
+        msk = mk;
+    };
+    load_plane(y_beg);
+    for (i64 y = y_beg; y < y_end; ++y) {
+        const u32 mkc = msk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 4) + 64 * j;
+            *(u32x4*)(wtile + lr * 256 + 16 * (cb ^ ((lr >> 4) & 15))) = ((mkc >> j) & 1u) ? stg[j] : (u32x4)(0u);
+        }
+        __syncthreads();
+        load_plane(y + 1);
+        u32 d[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(wtile + rd_off + rr * 256);
+        __syncthreads();                                  // the tile is free again: the next plane's data may be written
+        u32 o[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 A = d[15 - 4 * w], B = d[14 - 4 * w], Cc = d[13 - 4 * w], E = d[12 - 4 * w];
+            const u32 t0 = perm(B, A, 0x05010400u), t1 = perm(B, A, 0x07030602u);
+            const u32 u0 = perm(E, Cc, 0x05010400u), u1 = perm(E, Cc, 0x07030602u);
+            o[0][w] = perm(u0, t0, 0x05040100u);
+            o[1][w] = perm(u0, t0, 0x07060302u);
+            o[2][w] = perm(u1, t1, 0x05040100u);
+            o[3][w] = perm(u1, t1, 0x07060302u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            if (x >= W || zo >= D) continue;
+            const u32 vbi = vb[i];
+            u32x4 r = (u32x4)(0u);
+            if ((mkc >> (4 + i)) & 1u) {
+                r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
+                if (vbi != 0xffffu) {
+                    u32 mw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 b4 = (vbi >> (4 * w)) & 0xfu;
+                        mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) | ((b4 & 8u) ? 0xff000000u : 0u);
+                    }
+                    r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
+                }
+            }
+            __builtin_nontemporal_store(r, (u32x4*)(out + (x * H + y) * D + zo));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2' for rows that are not whole lines, FLAT form (grids with H * D % 128 == 0: every real shape of the reference whose longer mask
 // side is the height, e.g. Charminar 355 x 512 x 355).  For a fixed x the rows (x, y, :) of all planes follow each other in memory:
 // an output x-row is ONE contiguous stream of H * D bytes, f = y * D + z.  The kernel tiles that stream, not the planes: a tile is
@@ -1150,7 +1251,24 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         } else if (alignz)
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, true, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
-        else if (D % 16 == 0 && pm.c2 % 16 == 0)
+        else if (D % 16 == 0 && pm.c2 % 16 == 0 && W >= 256 && D >= 256 && ctx->tune_rot90_wide != 2 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0) {
+            // the 256 x 256-tile form (tune rot90_wide = 2: the 128-tile kernel).  Measured with tools/tybench.py on one box, variants
+            // interleaved (ms, 128-tile kernel -> this one): 1024^3 0.464 -> 0.430, 512^3 0.0665 -> 0.0608, 512 x 278 x 512 0.046 -> 0.035.
+            // Workgroups per CU: as many (up to 4) as leave a workgroup at least 4 planes -- 1024^3 likes 4 (0.430; 2: 0.445),
+            // 512^3 2 (0.061; 1: 0.075, 4: 0.068), 512 x 278 x 512 1 (0.035; 2: 0.041, 4: 0.045).
+            if (!ctx->rot90w_lds_set) {
+                PB3D_HIP(hipFuncSetAttribute((const void*)k_rot90w, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256));
+                ctx->rot90w_lds_set = true;
+            }
+            const i64 wt = ((D + 255) / 256) * ((W + 255) / 256);
+            int fillw = ctx->tune_misc[1] > 0 ? ctx->tune_misc[1] : 4;
+            if (ctx->tune_misc[1] <= 0)
+                while (fillw > 1 && planes_per_chunk(H, wt, ctx->cus, 32, fillw) < 4) fillw >>= 1;
+            const int TYw = planes_per_chunk(H, wt, ctx->cus, 32, fillw);
+            const TileMap wm = {(int)((D + 255) / 256), (int)((W + 255) / 256), (int)((H + TYw - 1) / TYw), 0};
+            hipLaunchKernelGGL(k_rot90w, dim3(tilemap_blocks(wm)), dim3(1024), 256 * 256, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
+                               pm.c0, pm.c2, W, H, D, TYw, wm);
+        } else if (D % 16 == 0 && pm.c2 % 16 == 0)
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
         else

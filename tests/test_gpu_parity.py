@@ -1428,3 +1428,21 @@ def test_label_chain_end_to_end(pb3d_gpu, golden, name):
         p1, c1, s1 = pb3d_gpu.voxel_grid_to_points_labels(full, pal, stride=st)
         p2, c2, s2 = pb3d_gpu.voxel_grid_to_points(rgb, stride=st)
         assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and tuple(s1) == tuple(s2), st
+
+
+def test_rot90_wide_tile_kernel(pb3d_gpu, oracle):
+    """the 256 x 256-tile form of the 90-degree step (grids from 256 x 256 planes up; tune rot90_wide = 2 pins the 128-tile kernel):
+    both bit-exact on whole and clipped tiles."""
+    rng = np.random.default_rng(41)
+    for (W, H, D) in [(256, 5, 256), (512, 3, 256), (304, 4, 304), (128, 6, 128), (272, 3, 304), (64, 2, 64)]:
+        for kind in ("binary", "bytes"):
+            g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "binary" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+            m = rng.random((H, W)) < 0.85
+            want = oracle.process_voxel_grid(g, m, 90)
+            for wide in (0, 2):
+                pb3d_gpu._lib.set_tuning("rot90_wide", wide)
+                try:
+                    got = pb3d_gpu.process_voxel_grid(g, m, 90)
+                finally:
+                    pb3d_gpu._lib.set_tuning("rot90_wide", 0)
+                assert np.array_equal(got, want), (W, H, D, kind, wide, int((got != want).sum()))

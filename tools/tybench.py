@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--fills", default="0,4,6,8,12,16")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--wide", default="0", help="comma list of tune rot90_wide values to interleave with the fills (0 = the 256 x 256-tile kernel where it applies, 2 = the 128-tile kernel)")
     a = ap.parse_args()
     rng = np.random.default_rng(5)
     for sh in a.shapes.split(","):
@@ -35,10 +36,12 @@ def main():
         dev.synth_occ(0, W, H, D, 0, d_occ)
         res = {}
         for r in range(a.rounds):
-            for f in a.fills.split(","):
-                pb3d._lib.set_tuning("misc1", int(f))
-                res.setdefault(f, []).append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t), a.reps), 4))
-        pb3d._lib.set_tuning("misc1", 0)
+            for wd in a.wide.split(","):
+                pb3d._lib.set_tuning("rot90_wide", int(wd))
+                for f in a.fills.split(","):
+                    pb3d._lib.set_tuning("misc1", int(f))
+                    res.setdefault(f"tile256:{f}" if wd == "0" else f"tile128:{f}", []).append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t), a.reps), 4))
+        pb3d._lib.set_tuning("misc1", 0); pb3d._lib.set_tuning("rot90_wide", 0)
         print(json.dumps({"shape": [W, H, D], "ms_by_fill": res}), flush=True)
         for b in (d_mwh, d_occ, d_o, d_t):
             b.free()
