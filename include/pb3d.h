@@ -95,7 +95,11 @@ int pb3d_rotate_carve(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, i
 
 /* ---- process_voxel_grid, reference utils/voxel_carving_utils.py:104-126 ------------------
  * for angle in range(0, 91, angle_interval): rotate-carve; cumulative.  The loop runs on
- * the device.  d_tmp: W*H*D bytes of scratch (ping-pong); d_out may not alias d_occ. */
+ * the device.  d_tmp: W*H*D bytes of scratch (ping-pong); d_out may not alias d_occ.
+ * Chains of two and more rotation steps (angle_interval <= 45) keep the volume BIT-SLICED between the steps (32 planes per dword,
+ * 1/4 B/voxel per middle step instead of 2; csrc/sliced.hip): the first kernel slices and checks that the data is 0 / 1, and the call
+ * waits on the host for that one kernel's verdict before it queues the steps (grids with other values take the byte chain, same
+ * results).  Everything else about the call is asynchronous on the context's stream, as for the other *_dev entries. */
 int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
                           const uint8_t* d_mask_wh, int angle_interval, uint8_t* d_out, uint8_t* d_tmp);
 int pb3d_process_grid(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, int64_t D,
@@ -286,6 +290,11 @@ int pb3d_orient_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t W, i
 int pb3d_count_nonzero_dev(pb3d_ctx* ctx, const uint8_t* d_bytes, int64_t n, int64_t* d_count);
 int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
                                 const uint8_t new_color[3], uint8_t* d_grid_rgb);
+/* The same for the label volume the LAST pb3d_label_* call on this context wrote, untouched since (PB3D_EINVAL otherwise): the
+ * labelling's 1-bit-per-voxel membership array is still on the device, so only the members' labels are read (9 MB of bits instead of
+ * 292 MB of labels at 512 x 278 x 512).  channels = 3: d_grid is a colour grid; 1: a label volume and new_color[0] the new label. */
+int pb3d_recolor_last_labelled_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                                   const uint8_t new_color[3], uint8_t* d_grid, int channels);
 /* d_out may be d_grid_rgb itself (in place: nothing but the painted cells is written). */
 int pb3d_extrude_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
                      int axis, int plus, int depth, const uint8_t* fill_color, uint8_t* d_out);

@@ -487,7 +487,8 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     const i64 rows = A0 * A1, P = (A2 + 63) / 64, nwords = rows * P;
     const i64 nchunks = (nwords + kWinPerBlock - 1) / kWinPerBlock;
     void *bits, *rootbits, *chunks;
-    PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nwords * 8, &bits));
+    PB3D_TRY(pb3d_scratch(ctx, 42, (size_t)nwords * 8, &bits));          // a slot of its own: the bits outlive the call (ctx->ccl_last)
+    ctx->ccl_last.valid = false;
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nwords * 8, &rootbits));
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)nchunks * 8 + 16, &chunks));
     const int dcap = stats ? (int)(cap < 16384 ? cap : 16384) : 0;
@@ -541,6 +542,10 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     PB3D_HIP(hipStreamSynchronize(ctx->stream));
     const i64 nroots = hb->nroots;
     *ncomp = nroots;
+    // the membership bits of THIS label volume stay where they are: a consumer that only needs the members' labels (recolouring) walks
+    // the 1-bit-per-voxel array instead of the 4-byte-per-voxel one
+    ctx->ccl_last.valid = true; ctx->ccl_last.labels = d_labels; ctx->ccl_last.bits = bits; ctx->ccl_last.rows = rows; ctx->ccl_last.A2 = A2;
+    ctx->ccl_last.P = P; ctx->ccl_last.gen = ctx->scratch_gen;
     if (stats && nroots <= dcap) {
         auto put = [&](i64 k, const int* b6, const unsigned long long* c4) {
             for (int a = 0; a < 3; ++a) { bbox_lo_hi[6 * k + a] = b6[a]; bbox_lo_hi[6 * k + 3 + a] = (i64)b6[3 + a] + 1; }

@@ -128,6 +128,28 @@ __global__ __launch_bounds__(256) void k_recolor_flagged(const int* __restrict__
     }
 }
 
+// the same from the membership bits of the labelling (ctx->ccl_last): one lane per 64-voxel window; only windows that hold members read
+// any label -- 9 MB of bits instead of 292 MB of labels at Taj 512
+__global__ __launch_bounds__(256) void k_recolor_bits(const u64* __restrict__ bits, const int* __restrict__ labels, const u8* __restrict__ comp_flag,
+                                                      i64 nwords, pb3d_magic mP, int A2, u8 r, u8 g, u8 b, u8* __restrict__ grid, int C) {
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < nwords; idx += (i64)gridDim.x * blockDim.x) {
+        u64 w = bits[idx];
+        if (!w) continue;
+        const u32 row = pb3d_div((u32)idx, mP), t = (u32)idx - row * mP.d;
+        const i64 base = (i64)row * A2 + 64 * (i64)t;
+        while (w) {
+            const int i = __ffsll((unsigned long long)w) - 1;
+            w &= w - 1;
+            const i64 v = base + i;
+            const int L = labels[v];
+            if (L > 0 && comp_flag[L - 1]) {
+                if (C == 1) grid[v] = r;
+                else { grid[3 * v] = r; grid[3 * v + 1] = g; grid[3 * v + 2] = b; }
+            }
+        }
+    }
+}
+
 // extrude_from_surface, axis 2 (reference :218-228): one wavefront per (x,y) column.  start = index of the
 // first occupied voxel from the chosen side (0 / D-1 for an empty column, like np.argmax), then `depth`
 // cells from there, inside the grid, are painted where valid[x,y].
@@ -394,7 +416,7 @@ int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int3
 }
 
 static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
-                        const uint8_t new_color[3], uint8_t* d_grid_rgb, int C) {
+                        const uint8_t new_color[3], uint8_t* d_grid_rgb, int C, bool last_labelled = false) {
     PB3D_REQUIRE(ctx && new_color && nvox >= 0 && ncomp >= 0, "pb3d_recolor_components: bad argument");
     if (nvox == 0 || ncomp == 0) return PB3D_OK;
     PB3D_REQUIRE(d_labels && comp_flag && d_grid_rgb, "pb3d_recolor_components: null buffer");
@@ -402,6 +424,16 @@ static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, co
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)ncomp, &f));
     PB3D_HIP(hipMemcpyAsync(f, comp_flag, (size_t)ncomp, hipMemcpyHostToDevice, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));   // comp_flag is a caller-owned host buffer
+    const pb3d_ctx::CclLast& cl = ctx->ccl_last;
+    const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows * cl.A2 == nvox && cl.gen == ctx->scratch_gen && cl.rows * cl.P < (1ll << 32);
+    PB3D_REQUIRE(!last_labelled || bits_ok, "pb3d_recolor_last_labelled: d_labels is not the volume the last pb3d_label_* call on this context wrote");
+    if (last_labelled) {
+        const i64 nwords = cl.rows * cl.P;
+        hipLaunchKernelGGL(k_recolor_bits, dim3(pb3d_stream_blocks(ctx, nwords, 256, 8)), dim3(256), 0, ctx->stream, (const u64*)cl.bits, d_labels,
+                           (const u8*)f, nwords, pb3d_make_magic((u32)cl.P), (int)cl.A2, new_color[0], new_color[1], new_color[2], d_grid_rgb, C);
+        PB3D_CHECK_LAUNCH();
+        return PB3D_OK;
+    }
     hipLaunchKernelGGL(k_recolor_flagged, dim3(pb3d_stream_blocks(ctx, nvox, 256, 8)), dim3(256), 0, ctx->stream, d_labels, (const u8*)f, nvox,
                        new_color[0], new_color[1], new_color[2], d_grid_rgb, C);
     PB3D_CHECK_LAUNCH();
@@ -411,6 +443,12 @@ static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, co
 int pb3d_recolor_components_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
                                 const uint8_t new_color[3], uint8_t* d_grid_rgb) {
     return recolor_impl(ctx, d_labels, nvox, comp_flag, ncomp, new_color, d_grid_rgb, 3);
+}
+
+int pb3d_recolor_last_labelled_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
+                                   const uint8_t new_color[3], uint8_t* d_grid, int channels) {
+    PB3D_REQUIRE(channels == 1 || channels == 3, "pb3d_recolor_last_labelled: channels is 1 (labels) or 3 (colours)");
+    return recolor_impl(ctx, d_labels, nvox, comp_flag, ncomp, new_color, d_grid, channels, true);
 }
 
 int pb3d_recolor_components_label_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "pb3d_label_value_stats_dev": [vp, vp, i64, i64, i64, C.c_uint8, vp, i64p, i64, i64p, i64p, i64p, intp],
     "pb3d_extrude_label_dev": [vp, vp, i64, i64, i64, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp],
     "pb3d_recolor_components_label_dev": [vp, vp, i64, u8p, i64, C.c_uint8, vp],
+    "pb3d_recolor_last_labelled_dev": [vp, vp, i64, u8p, i64, u8p, vp, C.c_int],
     "pb3d_orient_label_dev": [vp, vp, i64, i64, i64, vp],
     "pb3d_count_nonzero_dev": [vp, vp, i64, vp],
     "pb3d_recolor_components_dev": [vp, vp, i64, u8p, i64, u8p, vp],

@@ -514,14 +514,10 @@ def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis, label=False):
         means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column
         keep = {i for i, _ in sorted(means, key=lambda t: t[1])[:k]}
         flags = np.array([0 if (i + 1) in keep else 1 for i in range(n)], np.uint8)
-        if label:
-            _lib.check(_lib.load().pb3d_recolor_components_label_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n, int(new_color),
-                                                                     C.c_void_p(d_g.ptr)))
-            dev.sync()
-            return
-        nc = np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
-        _lib.check(_lib.load().pb3d_recolor_components_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n,
-                                                           _lib.p_u8(nc), C.c_void_p(d_g.ptr)))
+        # d_lab is what the labelling just wrote: the recolouring walks its membership bits (pb3d_recolor_last_labelled_dev)
+        nc = np.array([int(new_color), 0, 0], np.uint8) if label else np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
+        _lib.check(_lib.load().pb3d_recolor_last_labelled_dev(_lib.ctx(), C.c_void_p(d_lab.ptr), A0 * A1 * A2, _lib.p_u8(flags), n,
+                                                              _lib.p_u8(nc), C.c_void_p(d_g.ptr), 1 if label else 3))
         dev.sync()
     finally:
         d_lab.free()

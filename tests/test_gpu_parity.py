@@ -1446,3 +1446,32 @@ def test_rot90_wide_tile_kernel(pb3d_gpu, oracle):
                 finally:
                     pb3d_gpu._lib.set_tuning("rot90_wide", 0)
                 assert np.array_equal(got, want), (W, H, D, kind, wide, int((got != want).sum()))
+
+
+def test_recolour_entries_agree(pb3d_gpu, oracle):
+    """pb3d_recolor_components_dev (scans the whole label volume) and pb3d_recolor_last_labelled_dev (walks the labelling's membership
+    bits) write the same grid; the second refuses a label buffer that is not the last labelled one."""
+    import ctypes as C
+    from pb3d import device as dev
+    from pb3d.voxel_carving_utils import _label_stats
+    L = pb3d_gpu._lib
+    rng = np.random.default_rng(5)
+    col = np.array(pb3d_gpu.PART_COLORS["front_minarets"], np.uint8); new = np.array(pb3d_gpu.PART_COLORS["back_minarets"], np.uint8)
+    for shp in [(40, 33, 70), (17, 9, 130), (64, 64, 64)]:
+        grid = np.zeros(shp + (3,), np.uint8)
+        for _ in range(12):
+            lo = [int(rng.integers(0, s - 1)) for s in shp]; hi = [min(s, l + int(rng.integers(1, 9))) for s, l in zip(shp, lo)]
+            grid[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = col
+        want = oracle.recolor_backward_components(grid, col, new, k=3, sort_axis=1)
+        assert np.array_equal(pb3d_gpu.recolor_backward_components(grid, col, new, k=3, sort_axis=1), want), shp
+        d_g = dev.from_numpy(grid); d_a = dev.from_numpy(grid); d_b = dev.from_numpy(grid); d_lab = dev.DeviceBuffer(grid.size // 3 * 4)
+        n, _, cnt, sums = _label_stats(d_g, shp, col, d_lab)
+        flags = (rng.random(n) < 0.5).astype(np.uint8)
+        nvox = grid.size // 3
+        L.check(L.load().pb3d_recolor_components_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_a.ptr)))
+        L.check(L.load().pb3d_recolor_last_labelled_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_b.ptr), 3))
+        assert np.array_equal(d_a.download(grid.shape), d_b.download(grid.shape)), shp
+        with pytest.raises(L.Pb3dError, match="last pb3d_label"):
+            L.check(L.load().pb3d_recolor_last_labelled_dev(L.ctx(), C.c_void_p(d_a.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_b.ptr), 3))
+        for b in (d_g, d_a, d_b, d_lab):
+            b.free()
