@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_crop_cells(const CropDesc* __restrict__
 // other workgroup of the launch touches those voxels (disjoint boxes within a batch, disjoint planes within a component).
 __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* dst_rgb, const int* __restrict__ labels, i64 H, i64 D,
                                                          const CropDesc* __restrict__ descs, int ncomp, const u8* __restrict__ masks,
-                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol) {
+                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol, int abl) {
     extern __shared__ u32 lds[];
     const int tid = threadIdx.x;
     int c = 0;
@@ -82,28 +82,30 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
         for (int cell = tid; cell < ncell; cell += GTHREADS) {
             const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * C;
             u32 bits = 0;
-            for (int q0 = 0; q0 < np; q0 += 8) {
-                u32 any[8];
+            if (!(abl & 1)) {
+                // all 32 planes of the cell in flight at once: a dome crop is FOUR workgroups, so this phase is pure load latency
+                // (eight loads per batch: 0.31 ms of the dome's 0.5)
+                u32 any[32];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int q = q0 + k < np ? q0 + k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
+                for (int k = 0; k < 32; ++k) {
+                    const int q = k < np ? k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
                     const u8* v = p + (i64)q * rowb;
                     // a voxel's three bytes as ONE unaligned dword load (the fourth byte is the next voxel's; the volume's very last
-                    // voxel is read byte-wise): three byte loads per voxel and plane made this phase 100 us of a dome crop's 250
+                    // voxel is read byte-wise)
                     if (C == 1) any[k] = (u32)v[0];
                     else if (v + 4 <= vol_end) any[k] = *(const u32_a1*)v & 0x00ffffffu;
                     else any[k] = (u32)v[0] | (u32)v[1] | (u32)v[2];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (q0 + k < np) bits |= (u32)(any[k] != 0) << (q0 + k);
+                for (int k = 0; k < 32; ++k)
+                    if (k < np) bits |= (u32)(any[k] != 0) << k;
             }
             A[xs * pitch + zs] = bits & mb[xs];
             xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
         }
     }
     __syncthreads();
-    for (int s = 0; s < nrot; ++s) {
+    for (int s = 0; s < ((abl & 2) ? 0 : nrot); ++s) {
         const u32* ct = celltab + (i64)d.cell_off + (i64)s * ncell;
         int xs = xs0, zs = zs0;
         for (int base = tid; base < ncell; base += 8 * GTHREADS) {
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
             const u32 R = A[xs * pitch + zs];
             cnt += (unsigned long long)__popc(R);
             const i64 v0 = ((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs;
-            const u32 todo = ~R & live;
+            const u32 todo = (abl & 4) ? 0u : (~R & live);
             for (int q0 = 0; q0 < np; q0 += 8) {
                 if (!((todo >> q0) & 0xffu)) continue;
                 int lab[8];
@@ -285,7 +287,7 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
                 hipLaunchKernelGGL(k_crop_cells, gridc, dim3(256), 0, ctx->stream, (const CropDesc*)ddb, (const RotParams*)dpb, nrot, (u32*)dt);
             }
             hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
-                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D);
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_misc[0] >= 100 ? ctx->tune_misc[0] - 100 : 0);
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");

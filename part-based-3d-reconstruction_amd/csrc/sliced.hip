@@ -5,7 +5,7 @@
 // four taps (rot_common.h: lut_of), and a Y-plane never mixes with another (the rotation is about Y), so between two steps the
 // volume does not have to be bytes at all:
 //
-//     S32[g][x][z]  (u32, pitch Dp = D rounded up to 8)      bit q = occ[x][32 g + q][z],   g < G = ceil(H / 32)
+//     S32[g][x][z]  (u32, pitch Dp = D rounded up to 16)      bit q = occ[x][32 g + q][z],   g < G = ceil(H / 32)
 //
 // is 1/8 byte per voxel, a middle step reads and writes 1/4 B/voxel instead of 2, and neither side converts anything: the staged
 // footprint of a tile IS the dword the 32-plane multiplexer tree wants, and the tree's result IS the dword that is stored.  The chain:
@@ -50,50 +50,54 @@ __global__ __launch_bounds__(256) void k_s32_maskbits(const u8* __restrict__ mas
     bits[i] = b;
 }
 
-// u8 (W,H,D) -> S32.  One thread = 8 consecutive z of one (g, x): 32 planes x 8 bytes in, 8 dwords out.  mbits (optional): the
-// 0-degree carve of process_voxel_grid (reference :111-124, first iteration) as a bit mask on the way in.
+// u8 (W,H,D) -> S32.  One thread = 16 consecutive z of one (g, x): 32 planes x 16 bytes in (16-byte loads at whatever alignment the row
+// has), 16 dwords out.  mbits (optional): the 0-degree carve of process_voxel_grid (reference :111-124, first iteration) as a bit mask.
+typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_s32_slice(const u8* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ mbits, i64 W, i64 H,
                                                    i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total, int* __restrict__ flag) {
     const u32 idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
     const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
     const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
-    const i64 z = 8 * (i64)zb;
+    const i64 z = 16 * (i64)zb;
     const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
     const u8* base = in + ((i64)x * H + 32 * (i64)g) * D + z;
-    const bool whole = z + 8 <= D;
-    u32 lo[32], hi[32];
+    const bool whole = z + 16 <= D;
+    u32 hib = 0;
+    u32 w[4][4];                    // w[k][j]: byte c = planes 8 k .. 8 k + 7 of voxel z + 4 j + c
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        lo[q] = 0; hi[q] = 0;
-        if (q < np) {
-            if (whole) { const u32x2 v = *(const u32x2_a1*)(base + (i64)q * D); lo[q] = v.x; hi[q] = v.y; }
-            else {
-                for (int b = 0; b < 8 && z + b < D; ++b) {
-                    const u32 v = base[(i64)q * D + b];
-                    if (b < 4) lo[q] |= v << (8 * b); else hi[q] |= v << (8 * (b - 4));
+    for (int k = 0; k < 4; ++k) {
+        u32x4 d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            d[q] = (u32x4)(0u);
+            if (8 * k + q < np) {
+                const u8* p = base + (i64)(8 * k + q) * D;
+                if (whole) d[q] = *(const u32x4_a1*)p;
+                else {
+                    u32 t4[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16 && z + b < D; ++b) t4[b >> 2] |= (u32)p[b] << (8 * (b & 3));
+                    d[q].x = t4[0]; d[q].y = t4[1]; d[q].z = t4[2]; d[q].w = t4[3];
                 }
             }
         }
-    }
-    u32 hib = 0, wl[4], wh[4];
+        u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        u32 a = 0, b = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { a |= lo[8 * k + q] << q; b |= hi[8 * k + q] << q; hib |= lo[8 * k + q] | hi[8 * k + q]; }
-        wl[k] = a; wh[k] = b;
+        for (int q = 0; q < 8; ++q) {
+            a0 |= d[q].x << q; a1 |= d[q].y << q; a2 |= d[q].z << q; a3 |= d[q].w << q;
+            hib |= (d[q].x | d[q].y) | (d[q].z | d[q].w);
+        }
+        w[k][0] = a0; w[k][1] = a1; w[k][2] = a2; w[k][3] = a3;
     }
-    u32 vl[4], vh[4];
-    tr4x4(wl[0], wl[1], wl[2], wl[3], vl);      // vl[c]: byte k = planes 8 k .. 8 k + 7 of voxel z + c
-    tr4x4(wh[0], wh[1], wh[2], wh[3], vh);
     const u32 m = mbits ? mbits[row] : 0xffffffffu;
-    u32x4 o0, o1;
-    o0.x = vl[0] & m; o0.y = vl[1] & m; o0.z = vl[2] & m; o0.w = vl[3] & m;
-    o1.x = vh[0] & m; o1.y = vh[1] & m; o1.z = vh[2] & m; o1.w = vh[3] & m;
     u32* op = out + (i64)row * Dp + z;
-    *(u32x4*)op = o0;
-    *(u32x4*)(op + 4) = o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u32 v[4];
+        tr4x4(w[0][j], w[1][j], w[2][j], w[3][j], v);      // v[c]: byte k = planes 8 k .. 8 k + 7 of voxel z + 4 j + c
+        u32x4 o; o.x = v[0] & m; o.y = v[1] & m; o.z = v[2] & m; o.w = v[3] & m;
+        *(u32x4*)(op + 4 * j) = o;
+    }
     // a value other than 0 / 1: the chain cannot represent it (one relaxed look first: on such data every thread would hit the word)
     if ((hib & 0xfefefefeu) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag, 1);
 }
@@ -105,24 +109,26 @@ __global__ __launch_bounds__(256) void k_s32_unslice(const u32* __restrict__ in,
     if (idx >= total) return;
     const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
     const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
-    const i64 z = 8 * (i64)zb;
+    const i64 z = 16 * (i64)zb;
     const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
     const u32* ip = in + (i64)row * Dp + z;
-    const u32x4 a = *(const u32x4*)ip, b = *(const u32x4*)(ip + 4);
-    u32 vl[4], vh[4];
-    tr4x4(a.x, a.y, a.z, a.w, vl);               // vl[k]: byte c = planes 8 k .. 8 k + 7 of voxel z + c
-    tr4x4(b.x, b.y, b.z, b.w, vh);
+    u32 v[4][4];                    // v[j][k]: byte c = planes 8 k .. 8 k + 7 of voxel z + 4 j + c
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const u32x4 a = *(const u32x4*)(ip + 4 * j); tr4x4(a.x, a.y, a.z, a.w, v[j]); }
     u8* base = out + ((i64)x * H + 32 * (i64)g) * D + z;
-    const bool whole = z + 8 <= D;
+    const bool whole = z + 16 <= D;
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
         if (q >= np) break;
-        u32x2 v;
-        v.x = (vl[q >> 3] >> (q & 7)) & 0x01010101u; v.y = (vh[q >> 3] >> (q & 7)) & 0x01010101u;
+        u32x4 r;
+        r.x = (v[0][q >> 3] >> (q & 7)) & 0x01010101u; r.y = (v[1][q >> 3] >> (q & 7)) & 0x01010101u;
+        r.z = (v[2][q >> 3] >> (q & 7)) & 0x01010101u; r.w = (v[3][q >> 3] >> (q & 7)) & 0x01010101u;
         u8* dp = base + (i64)q * D;
-        if (whole) *(u32x2_a1*)dp = v;
-        else
-            for (int bb = 0; bb < 8 && z + bb < D; ++bb) dp[bb] = (u8)((bb < 4 ? v.x : v.y) >> (8 * (bb & 3)));
+        if (whole) *(u32x4_a1*)dp = r;
+        else {
+            const u32 t4[4] = {r.x, r.y, r.z, r.w};
+            for (int bb = 0; bb < 16 && z + bb < D; ++bb) dp[bb] = (u8)(t4[bb >> 2] >> (8 * (bb & 3)));
+        }
     }
 }
 
@@ -146,39 +152,37 @@ __device__ __forceinline__ void rgb4(u32 occ01, u32 C0, u32 C1, u32 C2, u32* o) 
 }
 
 // S32 -> (W,H,D,3) colours: apply_colored_mask_to_voxel_grid (reference :128-136) folded into the un-slicing -- voxel (x,y,z) gets
-// rgb_hw3[y, x] where its bit is set.  Same thread shape as k_s32_unslice; a thread writes 24 contiguous bytes per plane, a wave 1.5 KB.
+// rgb_hw3[y, x] where its bit is set.  Same thread shape as k_s32_unslice; a thread writes 48 contiguous bytes per plane, a wave 3 KB.
 __global__ __launch_bounds__(256) void k_s32_unslice_rgb(const u32* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ rgb_hw3, i64 W, i64 H,
                                                          i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total) {
     const u32 idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
     const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
     const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
-    const i64 z = 8 * (i64)zb;
+    const i64 z = 16 * (i64)zb;
     const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
     const u32* ip = in + (i64)row * Dp + z;
-    const u32x4 a = *(const u32x4*)ip, b = *(const u32x4*)(ip + 4);
-    u32 vl[4], vh[4];
-    tr4x4(a.x, a.y, a.z, a.w, vl);
-    tr4x4(b.x, b.y, b.z, b.w, vh);
+    u32 v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const u32x4 a = *(const u32x4*)(ip + 4 * j); tr4x4(a.x, a.y, a.z, a.w, v[j]); }
     u8* base = out + (((i64)x * H + 32 * (i64)g) * D + z) * 3;
     const u8* px = rgb_hw3 + ((32 * (i64)g) * W + x) * 3;
-    const bool whole = z + 8 <= D;
+    const bool whole = z + 16 <= D;
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
         if (q >= np) break;
         const u8* c = px + (i64)q * W * 3;
         const u32 R = c[0], G = c[1], B = c[2];
         const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
-        u32 o[6];
-        rgb4((vl[q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o);
-        rgb4((vh[q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o + 3);
+        u32 o[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rgb4((v[j][q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o + 3 * j);
         u8* dp = base + (i64)q * D * 3;
         if (whole) {
-            u32x2 v0, v1, v2;
-            v0.x = o[0]; v0.y = o[1]; v1.x = o[2]; v1.y = o[3]; v2.x = o[4]; v2.y = o[5];
-            *(u32x2_a1*)dp = v0; *(u32x2_a1*)(dp + 8) = v1; *(u32x2_a1*)(dp + 16) = v2;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { u32x4 r; r.x = o[4 * j]; r.y = o[4 * j + 1]; r.z = o[4 * j + 2]; r.w = o[4 * j + 3]; *(u32x4_a1*)(dp + 16 * j) = r; }
         } else {
-            for (int bb = 0; bb < 24 && z * 3 + bb < D * 3; ++bb) dp[bb] = (u8)(o[bb >> 2] >> (8 * (bb & 3)));
+            for (int bb = 0; bb < 48 && z * 3 + bb < D * 3; ++bb) dp[bb] = (u8)(o[bb >> 2] >> (8 * (bb & 3)));
         }
     }
 }
@@ -370,9 +374,9 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
     const int nrot = nsteps - 1;
     // (a pinned byte-tile kernel -- the parity tests pin each of them in turn -- means the byte chain)
     if (ctx->tune_sliced == 1 || ctx->tune_rotate_tile != 0 || nrot < (ctx->tune_sliced == 2 ? 1 : 2)) return PB3D_OK;
-    const i64 Dp = (D + 7) & ~(i64)7;
+    const i64 Dp = (D + 15) & ~(i64)15;
     const int G = (int)((H + 31) / 32);
-    const i64 nzb = Dp / 8;
+    const i64 nzb = Dp / 16;
     if (W >= 32768 || D >= 32768 || (i64)G * W * nzb >= (1ll << 31) || W * Dp >= (1ll << 31)) return PB3D_OK;
     const i64 shape[3] = {W, H, D};
     StepParams sp;

@@ -1471,7 +1471,7 @@ def test_recolour_entries_agree(pb3d_gpu, oracle):
         L.check(L.load().pb3d_recolor_components_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_a.ptr)))
         L.check(L.load().pb3d_recolor_last_labelled_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_b.ptr), 3))
         assert np.array_equal(d_a.download(grid.shape), d_b.download(grid.shape)), shp
-        with pytest.raises(L.Pb3dError, match="last pb3d_label"):
+        with pytest.raises(ValueError, match="last pb3d_label"):
             L.check(L.load().pb3d_recolor_last_labelled_dev(L.ctx(), C.c_void_p(d_a.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_b.ptr), 3))
         for b in (d_g, d_a, d_b, d_lab):
             b.free()
