@@ -21,7 +21,8 @@ namespace {
 struct CropDesc {
     int x0, y0, z0, Wc, Hc, Dc, id, g0, ng, pitch;
     u32 mask_off, cell_off;
-    int pad[4];
+    u32 slice_off;          // dwords: where this component's ng x ncell bit-sliced occupancy words start in the batch's slice buffer
+    int pad[3];
 };
 static_assert(sizeof(CropDesc) == 64, "CropDesc is 64 bytes");
 
@@ -44,11 +45,46 @@ __global__ __launch_bounds__(256) void k_crop_cells(const CropDesc* __restrict__
     }
 }
 
+// Occupancy of every crop, bit-sliced (any channel > 0, reference :190): slices[slice_off + g * ncell + cell] bit q = plane 32 g + q.
+// One thread per (component, plane group, cell), 32 loads in flight each, spread over the WHOLE chip: inside k_crop_chain the same
+// loads were issued by the four workgroups of a dome crop -- four CUs' worth of outstanding misses, 0.29 ms of the crop's 0.5.
+__global__ __launch_bounds__(256) void k_crop_slice(const u8* __restrict__ src_rgb, i64 H, i64 D, const CropDesc* __restrict__ descs, int ncomp,
+                                                    u32* __restrict__ slices, int C, i64 nvol) {
+    typedef u32 u32_a1 __attribute__((aligned(1)));
+    int c = 0;
+    while (c + 1 < ncomp && descs[c + 1].g0 <= (int)blockIdx.y) ++c;        // uniform
+    const CropDesc d = descs[c];
+    const int g = (int)blockIdx.y - d.g0;
+    const int ncell = d.Wc * d.Dc;
+    const int cell = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (cell >= ncell) return;
+    const int xs = cell / d.Dc, zs = cell - xs * d.Dc;
+    const int np = d.Hc - 32 * g < 32 ? d.Hc - 32 * g : 32;
+    const i64 rowb = D * C;
+    const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * C;
+    const u8* vol_end = src_rgb + nvol * C;
+    u32 any[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int q = k < np ? k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
+        const u8* v = p + (i64)q * rowb;
+        // a voxel's three bytes as ONE unaligned dword load (the fourth byte is the next voxel's; the volume's very last voxel byte-wise)
+        if (C == 1) any[k] = (u32)v[0];
+        else if (v + 4 <= vol_end) any[k] = *(const u32_a1*)v & 0x00ffffffu;
+        else any[k] = (u32)v[0] | (u32)v[1] | (u32)v[2];
+    }
+    u32 bits = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        if (k < np) bits |= (u32)(any[k] != 0) << k;
+    slices[(i64)d.slice_off + (i64)g * ncell + cell] = bits;
+}
+
 // src and dst may be the same volume (no __restrict__): a workgroup reads its crop's planes before it clears anything in them, and no
 // other workgroup of the launch touches those voxels (disjoint boxes within a batch, disjoint planes within a component).
 __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* dst_rgb, const int* __restrict__ labels, i64 H, i64 D,
                                                          const CropDesc* __restrict__ descs, int ncomp, const u8* __restrict__ masks,
-                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol, int abl) {
+                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol, int abl, const u32* __restrict__ slices) {
     extern __shared__ u32 lds[];
     const int tid = threadIdx.x;
     int c = 0;
@@ -72,36 +108,21 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
     // this thread's cells: tid, tid + 512, ... -- (xs, zs) advanced without a division per cell
     const int dx = GTHREADS / Dc, dz = GTHREADS - dx * Dc;
     const int xs0 = tid / Dc, zs0 = tid - xs0 * Dc;
-    const i64 rowb = D * C;                              // bytes from plane y to plane y + 1 of the grid (C = 3 colours, 1 label)
-    typedef u32 u32_a1 __attribute__((aligned(1)));
-    const u8* vol_end = src_rgb + nvol * C;
     // Every loop below is latency-bound if written cell by cell (a dependent global load per iteration: the first version spent
     // 220 us on a dome crop): loads are issued eight at a time before any of them is used.
-    {   // occupancy of the crop (any channel > 0, reference :190), 32 planes per cell, with the 0-degree carve (:124, first iteration)
+    {   // the crop's bit-sliced occupancy (k_crop_slice) with the 0-degree carve (:124, first iteration)
+        const u32* sl = slices + (i64)d.slice_off + (i64)g * ncell;
         int xs = xs0, zs = zs0;
-        for (int cell = tid; cell < ncell; cell += GTHREADS) {
-            const u8* p = src_rgb + (((i64)(d.x0 + xs) * H + d.y0 + 32 * g) * D + d.z0 + zs) * C;
-            u32 bits = 0;
-            if (!(abl & 1)) {
-                // all 32 planes of the cell in flight at once: a dome crop is FOUR workgroups, so this phase is pure load latency
-                // (eight loads per batch: 0.31 ms of the dome's 0.5)
-                u32 any[32];
+        for (int base = tid; base < ncell; base += 8 * GTHREADS) {
+            u32 w[8];
 #pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const int q = k < np ? k : np - 1;                // (a plane past the crop re-reads the last one; its bit is dropped)
-                    const u8* v = p + (i64)q * rowb;
-                    // a voxel's three bytes as ONE unaligned dword load (the fourth byte is the next voxel's; the volume's very last
-                    // voxel is read byte-wise)
-                    if (C == 1) any[k] = (u32)v[0];
-                    else if (v + 4 <= vol_end) any[k] = *(const u32_a1*)v & 0x00ffffffu;
-                    else any[k] = (u32)v[0] | (u32)v[1] | (u32)v[2];
-                }
+            for (int k = 0; k < 8; ++k) { const int cell = base + k * GTHREADS; w[k] = (cell < ncell && !(abl & 1)) ? sl[cell] : 0u; }
 #pragma unroll
-                for (int k = 0; k < 32; ++k)
-                    if (k < np) bits |= (u32)(any[k] != 0) << k;
+            for (int k = 0; k < 8; ++k) {
+                if (base + k * GTHREADS >= ncell) break;
+                A[xs * pitch + zs] = w[k] & mb[xs];
+                xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
             }
-            A[xs * pitch + zs] = bits & mb[xs];
-            xs += dx; zs += dz; if (zs >= Dc) { zs -= Dc; ++xs; }
         }
     }
     __syncthreads();
@@ -175,7 +196,6 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
     const int nrot = 90 / angle_interval;                 // len(range(0, 91, k)) - 1 rotation steps after the 0-degree carve
     // every crop's 32-plane slice (two buffers + mask bits) must fit the LDS and its offsets 16 bits: otherwise the caller's loop
     size_t lds_max = 0;
-    i64 ncells_total = 0;
     for (i64 k = 0; k < ncomp; ++k) {
         const i64* b = bbox_lo_hi + 6 * k;
         const i64 Wc = b[3] - b[0], Hc = b[4] - b[1], Dc = b[5] - b[2];
@@ -187,7 +207,6 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
         const size_t lds = (size_t)(2 * plane + Wc) * sizeof(u32);
         if (lds > (size_t)kMaxLds) return PB3D_OK;
         lds_max = lds > lds_max ? lds : lds_max;
-        ncells_total += Wc * Dc;
     }
     if (!ctx->guided_lds_set) {
         PB3D_HIP(hipFuncSetAttribute((const void*)k_crop_chain, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
@@ -230,29 +249,35 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
     keep_d.reserve(batches.size()); keep_p.reserve(batches.size());
     int rc = PB3D_OK;
     auto run = [&]() -> int {
-        size_t desc_bytes = 0, par_bytes = 0, tab_bytes = 0;
+        size_t desc_bytes = 0, par_bytes = 0, tab_bytes = 0, slice_bytes = 16;
         for (auto& be : batches) {
-            size_t cells = 0;
-            for (i64 k = be.first; k < be.second; ++k) { const i64* b = bbox_lo_hi + 6 * k; cells += (size_t)((b[3] - b[0]) * (b[5] - b[2])); }
+            size_t cells = 0, swords = 0;
+            for (i64 k = be.first; k < be.second; ++k) {
+                const i64* b = bbox_lo_hi + 6 * k;
+                cells += (size_t)((b[3] - b[0]) * (b[5] - b[2]));
+                swords += (size_t)((b[3] - b[0]) * (b[5] - b[2])) * (size_t)((b[4] - b[1] + 31) / 32);
+            }
+            slice_bytes = std::max(slice_bytes, swords * sizeof(u32));
             const size_t n = (size_t)(be.second - be.first);
             desc_bytes = std::max(desc_bytes, n * sizeof(CropDesc));
             par_bytes = std::max(par_bytes, n * (size_t)(nrot > 0 ? nrot : 1) * sizeof(RotParams));
             tab_bytes = std::max(tab_bytes, cells * (size_t)(nrot > 0 ? nrot : 1) * sizeof(u32));
         }
-        void *dd, *dt;
+        void *dd, *dt, *dsl;
         // every batch gets its own slice of the slot ([descriptors | step parameters], ONE upload): the upload of batch b + 1 must not
         // overwrite what batch b's kernels still read
         const size_t nb = batches.size();
         const size_t slice = ((desc_bytes + par_bytes) + 63) & ~(size_t)63;
         PB3D_TRY(pb3d_scratch(ctx, 36, slice * nb, &dd));
         PB3D_TRY(pb3d_scratch(ctx, 38, tab_bytes, &dt));
+        PB3D_TRY(pb3d_scratch(ctx, 43, slice_bytes, &dsl));
         for (size_t bi = 0; bi < nb; ++bi) {
             const i64 a = batches[bi].first, e = batches[bi].second;
             keep_d.emplace_back(); keep_p.emplace_back();
             std::vector<CropDesc>& ds = keep_d.back();
             std::vector<RotParams>& ps = keep_p.back();
             int g0 = 0;
-            u32 cell_off = 0;
+            u32 cell_off = 0, slice_off = 0;
             int maxcells = 0;
             for (i64 k = a; k < e; ++k) {
                 const i64* b = bbox_lo_hi + 6 * k;
@@ -261,7 +286,8 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
                 d.x0 = (int)b[0]; d.y0 = (int)b[1]; d.z0 = (int)b[2];
                 d.Wc = (int)(b[3] - b[0]); d.Hc = (int)(b[4] - b[1]); d.Dc = (int)(b[5] - b[2]);
                 d.id = (int)(k + 1); d.g0 = g0; d.ng = (d.Hc + 31) / 32; d.pitch = d.Dc | 1;
-                d.mask_off = (u32)mask_off[k]; d.cell_off = cell_off;
+                d.mask_off = (u32)mask_off[k]; d.cell_off = cell_off; d.slice_off = slice_off;
+                slice_off += (u32)(d.Wc * d.Dc) * (u32)d.ng;
                 g0 += d.ng;
                 cell_off += (u32)(d.Wc * d.Dc) * (u32)(nrot > 0 ? nrot : 1);
                 maxcells = std::max(maxcells, d.Wc * d.Dc);
@@ -286,8 +312,11 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
                 PB3D_REQUIRE(gridc.y <= 65535u, "pb3d_guided_carve: too many (component, step) pairs in a batch");
                 hipLaunchKernelGGL(k_crop_cells, gridc, dim3(256), 0, ctx->stream, (const CropDesc*)ddb, (const RotParams*)dpb, nrot, (u32*)dt);
             }
+            PB3D_REQUIRE(g0 <= 65535, "pb3d_guided_carve: too many plane groups in a batch");
+            hipLaunchKernelGGL(k_crop_slice, dim3((unsigned)((maxcells + 255) / 256), (unsigned)g0), dim3(256), 0, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), H, D,
+                               (const CropDesc*)ddb, n, (u32*)dsl, C, W * H * D);
             hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
-                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_misc[0] >= 100 ? ctx->tune_misc[0] - 100 : 0);
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_misc[0] >= 100 ? ctx->tune_misc[0] - 100 : 0, (const u32*)dsl);
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");

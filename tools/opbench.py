@@ -154,7 +154,11 @@ def main():
         for axis, nm in ((2, "z"), (0, "x")):
             for plus in (1, 0):
                 fn = lambda: L.check(lib.pb3d_extrude_dev(L.ctx(), C.c_void_p(d_o.ptr), S, S, S, C.c_void_p(d_v.ptr), S, axis, plus, 10, L.p_u8(fc), C.c_void_p(d_o.ptr)))
-                report("N2", f"extrude_from_surface axis {axis} {'+' if plus else '-'} depth 10, in place (k_extrude_{nm})", timeit(fn, a.reps), 3)
+                # the bytes an extrusion needs depend on the data (a column is scanned up to its first occupied voxel, then `depth` cells are
+                # written): no algorithmic-byte figure, the time only
+                ms = timeit(fn, a.reps)
+                print(json.dumps({"op": "N2", "name": f"extrude_from_surface axis {axis} {'+' if plus else '-'} depth 10, in place (k_extrude_{nm})", "size": S,
+                                  "ms": round(ms, 4), "alg_B_per_voxel": None, "note": "data-dependent traffic: scan to the first occupied voxel of every column under the mask"}), flush=True)
         from pb3d.voxel_carving_utils import _label_stats
         col = np.array(pb3d.PART_COLORS["full_building"], np.uint8)
         d_lab = dev.DeviceBuffer(nvox * 4)
@@ -164,7 +168,11 @@ def main():
         report("N2", "connected components of one colour + statistics (one pass, one round trip)", timeit(lab_fn, 2, warm=1), 7, {"components": out["n"]})
         flags = np.ones(max(1, out["n"]), np.uint8)
         fn = lambda: L.check(lib.pb3d_recolor_components_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), max(1, out["n"]), L.p_u8(fc), C.c_void_p(d_o.ptr)))
-        report("N2", "recolor_backward_components: recolour pass (k_recolor_flagged)", timeit(fn, 2, warm=1), 4)
+        report("N2", "recolor_backward_components: recolour pass over the label volume (k_recolor_flagged)", timeit(fn, 2, warm=1), 4)
+        fn2 = lambda: L.check(lib.pb3d_recolor_last_labelled_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), max(1, out["n"]), L.p_u8(fc), C.c_void_p(d_o.ptr), 3))
+        ms = timeit(fn2, 2, warm=1)
+        print(json.dumps({"op": "N2", "name": "recolor_backward_components: recolour pass over the labelling's membership bits (k_recolor_bits)", "size": S, "ms": round(ms, 4),
+                          "alg_B_per_voxel": 0.125, "note": "1 bit/voxel read + 4 B label and 3 B colour per member voxel"}), flush=True)
         for b in (d_o, d_v, d_lab):
             b.free()
     if "M7" in ops or "M8" in ops:
