@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_s32_unslice(const u32* __restrict__ in,
     const bool whole = z + 16 <= D;
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        if (q >= np) break;
+        if (q >= np) continue;
         u32x4 r;
         r.x = (v[0][q >> 3] >> (q & 7)) & 0x01010101u; r.y = (v[1][q >> 3] >> (q & 7)) & 0x01010101u;
         r.z = (v[2][q >> 3] >> (q & 7)) & 0x01010101u; r.w = (v[3][q >> 3] >> (q & 7)) & 0x01010101u;
@@ -152,37 +152,66 @@ __device__ __forceinline__ void rgb4(u32 occ01, u32 C0, u32 C1, u32 C2, u32* o) 
 }
 
 // S32 -> (W,H,D,3) colours: apply_colored_mask_to_voxel_grid (reference :128-136) folded into the un-slicing -- voxel (x,y,z) gets
-// rgb_hw3[y, x] where its bit is set.  Same thread shape as k_s32_unslice; a thread writes 48 contiguous bytes per plane, a wave 3 KB.
+// rgb_hw3[y, x] where its bit is set.  Same thread shape as k_s32_unslice: a thread owns 48 contiguous bytes per plane.  Stored
+// directly that is 16 bytes every 48 per instruction (each line touched by three instructions: 0.75 ms for the 3.2 GB of 1024^3);
+// the lanes' 48 bytes go through a wave-private LDS window and leave in ADDRESS order -- chunk c = 64 k + lane of the wave's 3 KB
+// belongs to lane c / 3 -- so every store instruction writes whole lines (the trick of k_color_apply16 / k_rot90<RGBOUT>).
 __global__ __launch_bounds__(256) void k_s32_unslice_rgb(const u32* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ rgb_hw3, i64 W, i64 H,
                                                          i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total) {
+    __shared__ u32x4 win[4][192];
     const u32 idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= total) return;
-    const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
+    const bool live = idx < total;                       // (every lane takes part in the exchange)
+    const u32 row = live ? pb3d_div(idx, mzb) : 0u, zb = live ? idx - row * mzb.d : 0u;
     const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
     const i64 z = 16 * (i64)zb;
     const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
-    const u32* ip = in + (i64)row * Dp + z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     u32 v[4][4];
+    if (live) {
+        const u32* ip = in + (i64)row * Dp + z;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const u32x4 a = *(const u32x4*)(ip + 4 * j); tr4x4(a.x, a.y, a.z, a.w, v[j]); }
-    u8* base = out + (((i64)x * H + 32 * (i64)g) * D + z) * 3;
+        for (int j = 0; j < 4; ++j) { const u32x4 a = *(const u32x4*)(ip + 4 * j); tr4x4(a.x, a.y, a.z, a.w, v[j]); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0u;
+    }
+    const i64 vbase = (((i64)x * H + 32 * (i64)g) * D + z) * 3;
     const u8* px = rgb_hw3 + ((32 * (i64)g) * W + x) * 3;
-    const bool whole = z + 16 <= D;
+    // a thread whose 16 voxels run past the row's end (D % 16 != 0) stores byte-wise and stays out of the exchange; so does a dead lane
+    const bool whole = live && z + 16 <= D;
+    // planes this WAVE walks: its lanes may sit in two plane groups (rows of different g), one of them the short last group -- walk the
+    // longest, predicate per lane.  The plane loop is unrolled (static indices into v[][]); planes past npmax are skipped wave-uniformly.
+    int npmax = live ? np : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) npmax = max(npmax, __shfl_xor(npmax, o));
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        if (q >= np) break;
-        const u8* c = px + (i64)q * W * 3;
-        const u32 R = c[0], G = c[1], B = c[2];
-        const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
+        if (q >= npmax) continue;
+        const bool mine = whole && q < np;
         u32 o[12];
+        if (live && q < np) {
+            const u8* c = px + (i64)q * W * 3;
+            const u32 R = c[0], G = c[1], B = c[2];
+            const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rgb4((v[j][q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o + 3 * j);
-        u8* dp = base + (i64)q * D * 3;
-        if (whole) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { u32x4 r; r.x = o[4 * j]; r.y = o[4 * j + 1]; r.z = o[4 * j + 2]; r.w = o[4 * j + 3]; *(u32x4_a1*)(dp + 16 * j) = r; }
+            for (int j = 0; j < 4; ++j) rgb4((v[j][q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o + 3 * j);
         } else {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) o[j] = 0u;
+        }
+        const i64 mybase = mine ? vbase + (i64)q * D * 3 : -1;
+        if (live && q < np && !whole) {
+            u8* dp = out + vbase + (i64)q * D * 3;
             for (int bb = 0; bb < 48 && z * 3 + bb < D * 3; ++bb) dp[bb] = (u8)(o[bb >> 2] >> (8 * (bb & 3)));
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { u32x4 t; t.x = o[4 * k]; t.y = o[4 * k + 1]; t.z = o[4 * k + 2]; t.w = o[4 * k + 3]; win[wv][3 * lane + k] = t; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = 64 * k + lane, L = c / 3, part = c - 3 * L;
+            const u32x4 t = win[wv][c];
+            const i64 lb = __shfl((long long)mybase, L);
+            if (lb >= 0) *(u32x4_a1*)(out + lb + 16 * part) = t;
         }
     }
 }
