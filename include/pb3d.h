@@ -253,8 +253,12 @@ int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, i
  * (the labels are in registers there).  The host arrays hold `cap` components; *stats_valid = 0 when there are more (only *ncomp and
  * the labels are then valid: call pb3d_component_stats_dev). */
 int pb3d_label_color_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
-                               int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum,
-                               int* stats_valid);
+                               int32_t* d_labels, int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count,
+                               int64_t* coord_sum, int* stats_valid);
+/* members_only = 1: the entries of d_labels at voxels that do NOT carry the colour are left UNWRITTEN (the zeros are more than half of the
+ * labelling's traffic).  Such a volume may only be consumed, before the next pb3d_label_* call on the context, by the entries that
+ * consult the labelling's membership bits: pb3d_guided_carve[_label]_dev and pb3d_recolor_last_labelled_dev (and by reading the labels
+ * of voxels known to carry the colour).  members_only = 0: a full label volume (0 elsewhere), as pb3d_label_color_dev writes. */
 int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0, int64_t A1, int64_t A2, int64_t ncomp,
                              int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum);
 int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
@@ -276,7 +280,8 @@ int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_l
  * (fill_label < 0: clear), recolouring and the output orientation.  Expanding a result with the palette gives the bytes of the RGB
  * entry (tests: label chain == RGB chain == the reference's stage digests). */
 int pb3d_label_value_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, uint8_t value, int32_t* d_labels,
-                               int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum, int* stats_valid);
+                               int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum,
+                               int* stats_valid);
 int pb3d_guided_carve_label_dev(pb3d_ctx* ctx, uint8_t* d_grid_lab, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                                 const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                                 int64_t* carved_counts, int* took);

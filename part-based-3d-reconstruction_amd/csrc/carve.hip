@@ -678,9 +678,8 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
     // up to eight such jobs: each leaves its carved occupancy in its own volume and ONE pass merges them (k_part_multi16); tune misc3 = 2
     // keeps the job-by-job keep-OR passes
     JobList jl; jl.n = 0;
-    int nrest = 0;
     for (int j = 0; j < njobs; ++j)
-        if (!job_skip[j]) { if (jl.n < 8) jl.j[jl.n++] = j; ++nrest; }
+        if (!job_skip[j] && jl.n < 8) jl.j[jl.n++] = j;
     if (multi) {
         void *carvedN = carved, *S = keep;
         for (int k = 0; k < jl.n; ++k) {

@@ -68,7 +68,9 @@ typedef u32 u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
 constexpr int kChunkVox = 1024;
 
 // C = 1: the grid is a 1-byte LABEL volume (row N3) and color24 the label -- a lane's 16 voxels are one 16-byte load.
-template <int C>
+// SPARSE: only the members' entries of the forest / label array are written (the 4 B/voxel of zeros for everybody else are most of this
+// pass's traffic: 292 MB of 511 at Taj 512).  Every later pass of the labelling touches members only; consumers must consult the bits.
+template <int C, bool SPARSE>
 __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i64 rows, int A2, int P, u32 color24, u64* __restrict__ bits,
                                                   int* __restrict__ parent) {
     const int lane = threadIdx.x & 63;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
                         const u32 s0 = upto ? (u32)(64 * t + 63 - __clzll((long long)upto)) : carry_start;
                         val = ~(int)(base + s0);
                     }
-                    parent[base + 64u * (u32)t + (u32)lane] = val;
+                    if (!SPARSE || val != 0) parent[base + 64u * (u32)t + (u32)lane] = val;
                 }
                 if ((w64 >> 63) && starts) carry_start = (u32)(64 * t + 63 - __clzll((long long)starts));
                 prevbit = (u32)(w64 >> 63);
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void k_ccl_stats(const u64* __restrict__ bits,
 
 static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
                             int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum,
-                            int* stats_valid, int C = 3) {
+                            int* stats_valid, int C = 3, bool members_only = false) {
     PB3D_REQUIRE(ctx && color && ncomp && A0 >= 0 && A1 >= 0 && A2 >= 0, "pb3d_label_color: bad argument");
     const i64 n = A0 * A1 * A2;
     *ncomp = 0;
@@ -503,12 +505,11 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     const pb3d_magic mP = pb3d_make_magic((u32)P), m1 = pb3d_make_magic((u32)A1);
     int* parent = (int*)d_labels;
 
-    if (C == 1)
-        hipLaunchKernelGGL(k_ccl_init<1>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24,
-                           (u64*)bits, parent);
-    else
-        hipLaunchKernelGGL(k_ccl_init<3>, dim3(pb3d_stream_blocks(ctx, rows, 4, 0)), dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24,
-                           (u64*)bits, parent);
+    {
+        const dim3 ig(pb3d_stream_blocks(ctx, rows, 4, 0));
+        auto kern = C == 1 ? (members_only ? k_ccl_init<1, true> : k_ccl_init<1, false>) : (members_only ? k_ccl_init<3, true> : k_ccl_init<3, false>);
+        hipLaunchKernelGGL(kern, ig, dim3(256), 0, ctx->stream, d_grid_rgb, rows, (int)A2, (int)P, color24, (u64*)bits, parent);
+    }
     PB3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ccl_merge, dim3(pb3d_stream_blocks(ctx, nwords, 256, 16)), dim3(256), 0, ctx->stream, (const u64*)bits, nwords, mP, m1, (int)A0,
                        (int)A1, (int)A2, parent);
@@ -545,7 +546,7 @@ static int label_color_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0
     // the membership bits of THIS label volume stay where they are: a consumer that only needs the members' labels (recolouring) walks
     // the 1-bit-per-voxel array instead of the 4-byte-per-voxel one
     ctx->ccl_last.valid = true; ctx->ccl_last.labels = d_labels; ctx->ccl_last.bits = bits; ctx->ccl_last.rows = rows; ctx->ccl_last.A2 = A2;
-    ctx->ccl_last.P = P; ctx->ccl_last.gen = ctx->scratch_gen;
+    ctx->ccl_last.P = P; ctx->ccl_last.gen = ctx->scratch_gen; ctx->ccl_last.members_only = members_only;
     if (stats && nroots <= dcap) {
         auto put = [&](i64 k, const int* b6, const unsigned long long* c4) {
             for (int a = 0; a < 3; ++a) { bbox_lo_hi[6 * k + a] = b6[a]; bbox_lo_hi[6 * k + 3 + a] = (i64)b6[3 + a] + 1; }
@@ -571,17 +572,17 @@ extern "C" int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, in
 }
 
 extern "C" int pb3d_label_color_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
-                                          int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count,
+                                          int32_t* d_labels, int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count,
                                           int64_t* coord_sum, int* stats_valid) {
     PB3D_REQUIRE(stats_valid != nullptr, "pb3d_label_color_stats: null output");
-    return label_color_impl(ctx, d_grid_rgb, A0, A1, A2, color, d_labels, ncomp, cap, bbox_lo_hi, count, coord_sum, stats_valid);
+    return label_color_impl(ctx, d_grid_rgb, A0, A1, A2, color, d_labels, ncomp, cap, bbox_lo_hi, count, coord_sum, stats_valid, 3, members_only != 0);
 }
 
 // the same on a 1-byte LABEL volume (row N3): components of the voxels whose label is `value`
 extern "C" int pb3d_label_value_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, uint8_t value,
-                                          int32_t* d_labels, int64_t* ncomp, int64_t cap, int64_t* bbox_lo_hi, int64_t* count,
+                                          int32_t* d_labels, int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count,
                                           int64_t* coord_sum, int* stats_valid) {
     PB3D_REQUIRE(stats_valid != nullptr, "pb3d_label_value_stats: null output");
     const uint8_t c3[3] = {value, 0, 0};
-    return label_color_impl(ctx, d_grid_lab, A0, A1, A2, c3, d_labels, ncomp, cap, bbox_lo_hi, count, coord_sum, stats_valid, 1);
+    return label_color_impl(ctx, d_grid_lab, A0, A1, A2, c3, d_labels, ncomp, cap, bbox_lo_hi, count, coord_sum, stats_valid, 1, members_only != 0);
 }

@@ -128,19 +128,28 @@ __global__ __launch_bounds__(256) void k_recolor_flagged(const int* __restrict__
     }
 }
 
-// the same from the membership bits of the labelling (ctx->ccl_last): one lane per 64-voxel window; only windows that hold members read
-// any label -- 9 MB of bits instead of 292 MB of labels at Taj 512
+// the same from the membership bits of the labelling (ctx->ccl_last): a wavefront takes 64 windows at a time (one lane each), then all
+// its lanes work on each non-empty one, a lane per voxel (coalesced label reads) -- only windows that hold members read any label:
+// 9 MB of bits instead of 292 MB of labels at Taj 512
+__device__ __forceinline__ u64 rl64(u64 v, int l) {
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)v, l);
+}
 __global__ __launch_bounds__(256) void k_recolor_bits(const u64* __restrict__ bits, const int* __restrict__ labels, const u8* __restrict__ comp_flag,
                                                       i64 nwords, pb3d_magic mP, int A2, u8 r, u8 g, u8 b, u8* __restrict__ grid, int C) {
-    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < nwords; idx += (i64)gridDim.x * blockDim.x) {
-        u64 w = bits[idx];
-        if (!w) continue;
-        const u32 row = pb3d_div((u32)idx, mP), t = (u32)idx - row * mP.d;
-        const i64 base = (i64)row * A2 + 64 * (i64)t;
-        while (w) {
-            const int i = __ffsll((unsigned long long)w) - 1;
-            w &= w - 1;
-            const i64 v = base + i;
+    const int lane = threadIdx.x & 63;
+    const i64 nwaves = (i64)gridDim.x * 4, wid = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (i64 c0 = wid * 64; c0 < nwords; c0 += nwaves * 64) {
+        const i64 idx = c0 + lane;
+        const u64 mine = idx < nwords ? bits[idx] : 0ull;
+        u64 todo = __ballot(mine != 0ull);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const u64 w = rl64(mine, src);
+            if (!((w >> lane) & 1ull)) continue;
+            const u32 widx = (u32)(c0 + src);
+            const u32 row = pb3d_div(widx, mP), t = widx - row * mP.d;
+            const i64 v = (i64)row * A2 + 64 * (i64)t + lane;
             const int L = labels[v];
             if (L > 0 && comp_flag[L - 1]) {
                 if (C == 1) grid[v] = r;
@@ -435,7 +444,7 @@ static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, co
     PB3D_REQUIRE(!last_labelled || bits_ok, "pb3d_recolor_last_labelled: d_labels is not the volume the last pb3d_label_* call on this context wrote");
     if (last_labelled) {
         const i64 nwords = cl.rows * cl.P;
-        hipLaunchKernelGGL(k_recolor_bits, dim3(pb3d_stream_blocks(ctx, nwords, 256, 8)), dim3(256), 0, ctx->stream, (const u64*)cl.bits, d_labels,
+        hipLaunchKernelGGL(k_recolor_bits, dim3(pb3d_stream_blocks(ctx, (nwords + 63) / 64, 4, 8)), dim3(256), 0, ctx->stream, (const u64*)cl.bits, d_labels,
                            (const u8*)f, nwords, pb3d_make_magic((u32)cl.P), (int)cl.A2, new_color[0], new_color[1], new_color[2], d_grid_rgb, C);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void k_crop_slice(const u8* __restrict__ src_r
 // other workgroup of the launch touches those voxels (disjoint boxes within a batch, disjoint planes within a component).
 __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* dst_rgb, const int* __restrict__ labels, i64 H, i64 D,
                                                          const CropDesc* __restrict__ descs, int ncomp, const u8* __restrict__ masks,
-                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol, int abl, const u32* __restrict__ slices) {
+                                                         const u32* __restrict__ celltab, int nrot, unsigned long long* __restrict__ counts, int restore, int C, i64 nvol, int abl, const u32* __restrict__ slices,
+                                                         const u64* __restrict__ mbits64, int P) {
     extern __shared__ u32 lds[];
     const int tid = threadIdx.x;
     int c = 0;
@@ -157,8 +158,19 @@ __global__ __launch_bounds__(GTHREADS) void k_crop_chain(const u8* src_rgb, u8* 
             for (int q0 = 0; q0 < np; q0 += 8) {
                 if (!((todo >> q0) & 0xffu)) continue;
                 int lab[8];
+                if (mbits64) {
+                    // the labelling's membership bits (word (row, z / 64), bit z % 64) say which voxels carry a label at all: a label volume
+                    // written for the members only (pb3d_label_*_stats_dev with members_only) holds nothing elsewhere
+                    const i64 row0 = (i64)(d.x0 + xs) * H + d.y0 + 32 * g, zz = d.z0 + zs;
+                    u64 mw[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) lab[k] = ((todo >> (q0 + k)) & 1u) ? labels[v0 + (i64)(q0 + k) * D] : 0;
+                    for (int k = 0; k < 8; ++k) mw[k] = ((todo >> (q0 + k)) & 1u) ? mbits64[(row0 + q0 + k) * P + (zz >> 6)] : 0ull;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) lab[k] = ((mw[k] >> (zz & 63)) & 1ull) ? labels[v0 + (i64)(q0 + k) * D] : 0;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) lab[k] = ((todo >> (q0 + k)) & 1u) ? labels[v0 + (i64)(q0 + k) * D] : 0;
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (lab[k] == d.id) { u8* o = dst_rgb + C * (v0 + (i64)(q0 + k) * D); o[0] = 0; if (C == 3) { o[1] = 0; o[2] = 0; } }
@@ -208,6 +220,11 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
         if (lds > (size_t)kMaxLds) return PB3D_OK;
         lds_max = lds > lds_max ? lds : lds_max;
     }
+    // labels of the last labelling on this context: its membership bits are still on the device
+    const pb3d_ctx::CclLast& cl = ctx->ccl_last;
+    const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows == W * H && cl.A2 == D && cl.gen == ctx->scratch_gen;
+    const u64* mb64 = bits_ok ? (const u64*)cl.bits : nullptr;
+    const int mbP = bits_ok ? (int)cl.P : 0;
     if (!ctx->guided_lds_set) {
         PB3D_HIP(hipFuncSetAttribute((const void*)k_crop_chain, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         ctx->guided_lds_set = true;
@@ -316,7 +333,7 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
             hipLaunchKernelGGL(k_crop_slice, dim3((unsigned)((maxcells + 255) / 256), (unsigned)g0), dim3(256), 0, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), H, D,
                                (const CropDesc*)ddb, n, (u32*)dsl, C, W * H * D);
             hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
-                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_misc[0] >= 100 ? ctx->tune_misc[0] - 100 : 0, (const u32*)dsl);
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_misc[0] >= 100 ? ctx->tune_misc[0] - 100 : 0, (const u32*)dsl, mb64, mbP);
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");

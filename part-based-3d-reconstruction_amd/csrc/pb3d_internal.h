@@ -81,7 +81,7 @@ struct pb3d_ctx {
     struct S32Cache { bool valid; u64 gen; i64 W, D; int ns; double p[32 * 8]; } s32_cache;
     hipEvent_t s32_ev;          // recorded behind the slice kernel's "not 0/1" flag copy
     // membership bits of the last labelled volume (csrc/ccl.hip, scratch slot 42): word row * P + t, bit = voxel is a member
-    struct CclLast { bool valid; const void* labels; const void* bits; i64 rows, A2, P; u64 gen; } ccl_last;
+    struct CclLast { bool valid; const void* labels; const void* bits; i64 rows, A2, P; u64 gen; bool members_only; } ccl_last;
     void* flag_ring;            // the ring of "value > 1 seen" flag words of the generic-angle steps (scratch slot 15) and its position
     u64 flag_gen;
     hipStream_t aux_stream;     // table builds that overlap the main stream's kernels

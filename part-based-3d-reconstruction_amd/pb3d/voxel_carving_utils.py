@@ -312,21 +312,24 @@ def _component_stats(d_labels, shape3, n):
     return bbox[:n], cnt[:n], sums[:n]
 
 
-def _label_stats(d_grid, shape3, color_u8, d_labels, cap=1024):
+def _label_stats(d_grid, shape3, color_u8, d_labels, cap=1024, members_only=False):
     """_label + _component_stats in one device pass and one host round trip (pb3d_label_color_stats_dev); scenes with more than
-    `cap` components take the separate statistics pass."""
+    `cap` components take the separate statistics pass.  members_only: d_labels is written at the colour's voxels only (for the
+    consumers that walk the labelling's membership bits: the fused component loop and the recolouring)."""
     A0, A1, A2 = shape3
     n = C.c_int64(0); ok = C.c_int(0)
     bbox = np.zeros((cap, 6), np.int64); cnt = np.zeros(cap, np.int64); sums = np.zeros((cap, 3), np.int64)
     if isinstance(color_u8, (int, np.integer)):          # a 1-byte label volume (pb3d.labels): components of one label value
         _lib.check(_lib.load().pb3d_label_value_stats_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, int(color_u8), C.c_void_p(d_labels.ptr),
-                                                          C.byref(n), cap, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
+                                                          C.byref(n), cap, 1 if members_only else 0, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
                                                           sums.ctypes.data_as(_lib.i64p), C.byref(ok)))
     else:
         _lib.check(_lib.load().pb3d_label_color_stats_dev(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, _lib.p_u8(color_u8), C.c_void_p(d_labels.ptr),
-                                                          C.byref(n), cap, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
+                                                          C.byref(n), cap, 1 if members_only else 0, bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p),
                                                           sums.ctypes.data_as(_lib.i64p), C.byref(ok)))
     if not ok.value:
+        if members_only:        # more components than `cap`: the separate statistics pass reads the WHOLE label volume -- label again, in full
+            return _label_stats(d_grid, shape3, color_u8, d_labels, cap=cap, members_only=False)
         return (n.value,) + _component_stats(d_labels, shape3, n.value)
     return n.value, bbox[:n.value], cnt[:n.value], sums[:n.value]
 
@@ -350,7 +353,8 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
     tmp = []
     try:
         cu8 = _color_u8(target_color) if label is None else int(label)
-        num, bbox, _, _ = _label_stats(d_col, (W, H, D), cu8, d_lab) if cu8 is not None else (0, None, None, None)
+        # (labels written at the component voxels only: the fused loop below consults the labelling's membership bits)
+        num, bbox, _, _ = _label_stats(d_col, (W, H, D), cu8, d_lab, members_only=True) if cu8 is not None else (0, None, None, None)
         print(f"[{target_color}] 3D components: {num}")
         if not num:
             return d_col
@@ -378,7 +382,9 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
         if counts is None and label is not None:
             raise ValueError("left_right_guided_carve on labels: a component's 32-plane slice does not fit the LDS (or angle < 0); use the RGB form")
         if counts is None:
-            # a crop too large for the LDS-resident chain (or an empty angle loop): component by component, into a copy
+            # a crop too large for the LDS-resident chain (or an empty angle loop): component by component, into a copy -- these entries
+            # read labels at every voxel of a crop, so the volume is labelled again, in full
+            _label(d_col, (W, H, D), cu8, d_lab)
             d_carved = dev.DeviceBuffer(nbytes)
             _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), nbytes))
             vmax = int(max((b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]) for b in bbox))
@@ -508,7 +514,7 @@ def _recolor_dev(d_g, shape3, color, new_color, k, sort_axis, label=False):
         return
     d_lab = dev.DeviceBuffer(A0 * A1 * A2 * 4)
     try:
-        n, _, cnt, sums = _label_stats(d_g, (A0, A1, A2), cu8, d_lab)
+        n, _, cnt, sums = _label_stats(d_g, (A0, A1, A2), cu8, d_lab, members_only=True)
         if n == 0:
             return
         means = [(i + 1, sums[i, sort_axis] / cnt[i]) for i in range(n)]        # np.mean of an int64 column

@@ -458,6 +458,14 @@ def test_connected_components_row_frame_shapes(pb3d_gpu, oracle):
                     assert n2 == n and np.array_equal(d_l2.download(shp, np.int32), want), (shp, dens, cap)
                     assert np.array_equal(b2, bbox) and np.array_equal(c2, cnt) and np.array_equal(s2, sums), (shp, dens, cap)
                     d_l2.free()
+                # members_only: the zeros of the non-members are not written (poisoned buffer), the members' labels and the statistics are the same
+                d_l3 = dev.from_numpy(np.full(shp, -7, np.int32))
+                n3, b3, c3, s3 = _label_stats(d_g, shp, col, d_l3, cap=4096, members_only=True)
+                got3 = d_l3.download(shp, np.int32)
+                # (more components than the capacity: the call falls back to a FULL labelling -- zeros outside)
+                assert n3 == n and np.array_equal(got3[mask], want[mask]) and np.all(got3[~mask] == (-7 if n <= 4096 else 0)), (shp, dens)
+                assert np.array_equal(b3, bbox) and np.array_equal(c3, cnt) and np.array_equal(s3, sums), (shp, dens)
+                d_l3.free()
             d_g.free(); d_lab.free()
 
 
