@@ -166,6 +166,12 @@ def main():
         def lab_fn():
             out["n"] = _label_stats(d_col, (S, S, S), col, d_lab)[0]
         report("N2", "connected components of one colour + statistics (one pass, one round trip)", timeit(lab_fn, 2, warm=1), 7, {"components": out["n"]})
+        def lab_fn2():
+            out["n"] = _label_stats(d_col, (S, S, S), col, d_lab, members_only=True)[0]
+        members = int(np.count_nonzero(np.all(dev.DeviceGrid(d_col, (S, S, S, 3)).numpy() == col, axis=-1))) if S <= 512 else None
+        report("N2", "... labels written for the colour's voxels only (members_only: what the notebook-1 chain uses)", timeit(lab_fn2, 2, warm=1), 3,
+               {"components": out["n"], "member_voxels": members, "note": "3 B/voxel read + 4 B per MEMBER voxel written (not priced)"})
+        lab_fn()
         flags = np.ones(max(1, out["n"]), np.uint8)
         fn = lambda: L.check(lib.pb3d_recolor_components_dev(L.ctx(), C.c_void_p(d_lab.ptr), nvox, L.p_u8(flags), max(1, out["n"]), L.p_u8(fc), C.c_void_p(d_o.ptr)))
         report("N2", "recolor_backward_components: recolour pass over the label volume (k_recolor_flagged)", timeit(fn, 2, warm=1), 4)
