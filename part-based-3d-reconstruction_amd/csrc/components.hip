@@ -208,6 +208,37 @@ __global__ __launch_bounds__(256) void k_extrude_x(const u8* src, u8* dst, const
         bool v = false;
         if (mine < n) { const i64 y = mine / D, z = mine - y * D; v = valid_hw[y * Wmask + z] != 0; }
         u64 todo = __ballot(v);
+        if (__popcll(todo) > 12) {
+            // a DENSE mask (most of the 64 columns are under it): one lane per column, eight planes of the scan in flight -- taking the
+            // columns one by one with the whole wave would serialise 64 scans (7.7 ms instead of 1.2 at 1024^3 under an all-ones mask)
+            if (v) {
+                const i64 y = mine / D, z = mine - y * D;
+                i64 start = plus ? 0 : W - 1;
+                for (i64 j0 = 0; j0 < W; j0 += 8) {
+                    u32 on[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const i64 j = j0 + k < W ? j0 + k : W - 1;
+                        const i64 x = plus ? j : W - 1 - j;
+                        const u8* p = src + ((x * H + y) * D + z) * C;
+                        on[k] = C == 1 ? (u32)p[0] : ((u32)p[0] | (u32)p[1] | (u32)p[2]);
+                    }
+                    int hit = -1;
+#pragma unroll
+                    for (int k = 7; k >= 0; --k)
+                        if (on[k] && j0 + k < W) hit = k;
+                    if (hit >= 0) { const i64 j = j0 + hit; start = plus ? j : W - 1 - j; break; }
+                }
+                for (int d = 0; d < depth; ++d) {
+                    const i64 x = plus ? start + d : start - d;
+                    if (x < 0 || x >= W) continue;
+                    u8* o = dst + ((x * H + y) * D + z) * C;
+                    o[0] = has_color ? cr : (u8)0;
+                    if (C == 3) { o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0; }
+                }
+            }
+            continue;
+        }
         while (todo) {
             const int k = __ffsll((unsigned long long)todo) - 1;
             todo &= todo - 1;
