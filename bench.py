@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-planes", type=int, default=0, help="X-planes of the grid the CPU baseline is timed on (0 = all of them)")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rotation-chain figures reported next to the headline (N = 1 only)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank carves its own full S^3 grid (default: the ONE "
                     "S^3 grid of the BASELINE metric is split into X-slabs = strong scaling)")
     args = ap.parse_args()
@@ -326,6 +327,38 @@ def main():
             cp.barrier()      # every rank leaves the phase together; still under the watchdog
         finally:
             done.set()
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # Not part of `value`: the other kernels of the path on the same 1024^3 grid, timed after the headline figure is final (HIP events,
+        # 3 repetitions each, device-resident) -- the rotation chains of process_voxel_grid / global_carve (reference
+        # utils/voxel_carving_utils.py:104-126, :269-298), which run bit-sliced between their steps.
+        nvox = S * S * S
+        d_occ = dev.DeviceBuffer(nvox); d_o1 = dev.DeviceBuffer(nvox); d_tmp = dev.DeviceBuffer(nvox)
+        d_bhw = dev.DeviceBuffer(S * S); d_rgb = dev.DeviceBuffer(S * S * 3)
+        dev.synth_occ(0, S, S, S, 0, d_occ)
+        dev.synth_mask16(S, d_binary_hw=d_bhw, d_rgb_hw3=d_rgb)
+
+        def ms_of(fn, reps=3):
+            fn(); dev.sync()
+            a, b = dev.Event(), dev.Event()
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record(); dev.sync()
+            return round(b.elapsed_ms_since(a) / reps, 4)
+
+        ex = {"note": "1024^3 occupancy / colour grids, device-resident, ms per call; sweeps = rotation steps executed (the 0-degree step is folded)"}
+        for ai in (90, 45, 5):
+            ex[f"process_voxel_grid_angle{ai}_ms"] = ms_of(lambda: dev.process_grid(d_occ, S, S, S, d_mwh, ai, d_o1, d_tmp))
+        ex["process_voxel_grid_angle5_sweeps"] = 18
+        ex["process_voxel_grid_angle5_moved_B_per_voxel"] = 2.25 + 0.25 * 18
+        for ai in (90, 45):
+            ex[f"global_carve_angle{ai}_ms"] = ms_of(lambda: dev.global_carve(d_bhw, d_rgb, S, S, ai, d_full))
+        dev.carve_mask(d_in, planes, S, S, 3, d_mslab, d_out)      # d_full holds the carve again (the CPU check below reads it)
+        dev.sync()
+        out["extras"] = ex
+        for b in (d_occ, d_o1, d_tmp, d_bhw, d_rgb):
+            b.free()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         lab_planes = min(S, args.cpu_planes) if args.cpu_planes > 0 else S      # default: the WHOLE grid

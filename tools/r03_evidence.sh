@@ -9,9 +9,9 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -c 700 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_prof.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/bench_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_prof.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/bench_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/bench_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_write.log 2>&1
 cd $R
 echo "== opbench"; python3 tools/opbench.py > $O/opbench.jsonl 2> $O/opbench.err
 python3 tools/opbench.py --size 512 --ops M3,M5,N2 > $O/opbench_512.jsonl 2>> $O/opbench.err
