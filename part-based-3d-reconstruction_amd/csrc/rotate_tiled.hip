@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90_flat(const u8* __res
             const u32 y = pb3d_div(f, mD), z = f - y * mD.d;
             const i64 n0 = (i64)c0 - (i64)z;
             stg[j] = (u32x4)(0u);
-            if (live && cmode != 0 && n0 >= 0 && n0 < W) {
+            if (live && (i64)f < HD && cmode != 0 && n0 >= 0 && n0 < W) {          // (f >= H * D: the ragged last segment of a stream that is not whole lines)
                 const u8* sp = in + (n0 * H + (i64)y) * D + scol;
                 // a ragged piece may be read whole as long as it stays inside the volume: the bytes beyond the row belong to
                 // the neighbouring row and are dropped by the validity bits (their source column is outside [0, D))
@@ -723,14 +723,15 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90_flat(const u8* __res
         msk = mk;
         // this thread's output piece: bytes j = 16 zg .. 16 zg + 15 of the segment = voxels (y, z .. ) and, past a row end, (y + 1, 0 ..)
         const u32 f = (u32)(128 * s) + (u32)(16 * zg);
-        const u32 y = live ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+        const bool pin = live && (i64)f < HD;                               // this thread's piece lies inside the stream (H * D % 16 == 0: whole or absent)
+        const u32 y = pin ? pb3d_div(f, mD) : 0u, z = pin ? f - y * mD.d : 0u;
         const int nA = (i64)z + 16 <= D ? 16 : (int)(D - (i64)z);          // bytes of the piece in plane y (D >= 16)
         const u32 lowA = (1u << nA) - 1u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const i64 x = x0 + 4 * xg + i;
             u32 k = 0;
-            if (live && x < W) {
+            if (pin && x < W) {
                 u32 bits = vwin(x, (i64)z);
                 if (nA < 16) bits |= vwin(x, (i64)z - D);
                 if (bits) {
@@ -790,7 +791,8 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90_flat(const u8* __res
                     r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
                 }
             }
-            __builtin_nontemporal_store(r, (u32x4*)(out + x * HD + 128 * s + 16 * zg));     // a whole aligned piece of a whole aligned line
+            if (128 * s + 16 * zg < HD)                                                       // (absent only in a ragged last segment)
+                __builtin_nontemporal_store(r, (u32x4*)(out + x * HD + 128 * s + 16 * zg));     // a whole aligned piece (of a whole aligned line when H * D % 128 == 0)
         }
     }
 }
@@ -1056,7 +1058,8 @@ __global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colo
             stg_a = (live && n0 >= 0 && n0 < W) ? A[n0 * H + (i64)y] : 0u;
         }
         const u32 f = (u32)(128 * s) + (u32)(16 * zg);
-        const u32 y = live ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+        const bool pin = live && (i64)f < HD;                               // this thread's piece lies inside the stream (H * D % 16 == 0: whole or absent)
+        const u32 y = pin ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
         stg_nA = (i64)z + 16 <= D ? 16 : (int)(D - (i64)z);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1228,7 +1231,10 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         // rows that are not whole lines, but all rows of a plane at one phase: the plane-shifted tile grid (k_rot90<.., ALIGNZ>)
         // ... or, better, the stream of each x-row tiled in whole lines (k_rot90_flat); tune misc2: 2 = neither, 3 = the plane-shifted grid
         const bool lines_ok = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
-        const bool flat = lines_ok && ctx->tune_misc[2] != 3 && H * D < (1ll << 31) && (((uintptr_t)d_out) & 127u) == 0;
+        // (round 3) the flat form also takes streams that are whole 16-byte pieces but not whole lines (H * D % 16 == 0, e.g. 500 x 400 x 500):
+        // the last segment of an x-row's stream is ragged, and the rows of odd x start mid-line (their stores are aligned pieces, not lines)
+        const bool flat16 = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 16 == 0 && D >= 128 && ctx->tune_misc[2] != 2 && ctx->tune_misc[2] != 4;
+        const bool flat = (lines_ok || flat16) && ctx->tune_misc[2] != 3 && H * D < (1ll << 31) - 256 && (((uintptr_t)d_out) & 127u) == 0;
         const bool alignz = lines_ok && !flat;
         const i64 nzt = alignz ? (D + 127 + 127) / 128 : (D + 127) / 128;
         const i64 tiles = nzt * ((W + 127) / 128);
@@ -1243,7 +1249,7 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm, d_rgb_hw3);
         } else if (flat) {
-            const i64 nseg = H * D / 128, nxt = (W + 127) / 128;
+            const i64 nseg = (H * D + 127) / 128, nxt = (W + 127) / 128;
             const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
             const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
             hipLaunchKernelGGL(k_rot90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,

@@ -1483,3 +1483,22 @@ def test_recolour_entries_agree(pb3d_gpu, oracle):
             L.check(L.load().pb3d_recolor_last_labelled_dev(L.ctx(), C.c_void_p(d_a.ptr), nvox, L.p_u8(flags), n, L.p_u8(new), C.c_void_p(d_b.ptr), 3))
         for b in (d_g, d_a, d_b, d_lab):
             b.free()
+
+
+def test_rot90_flat_ragged_streams(pb3d_gpu, oracle):
+    """the flat 90-degree kernel on x-row streams that are whole 16-byte pieces but not whole lines (H * D % 16 == 0, % 128 != 0, e.g.
+    500 x 400 x 500): ragged last segment, rows of odd x starting mid-line -- against the tile kernel (tune misc2 = 4) and the oracle."""
+    rng = np.random.default_rng(43)
+    for (W, H, D) in [(200, 12, 204), (260, 10, 136), (131, 4, 140), (300, 8, 250), (150, 24, 202)]:
+        assert (H * D) % 16 == 0 and (H * D) % 128 != 0 and D >= 128
+        for kind in ("binary", "bytes"):
+            g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "binary" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
+            m = rng.random((H, W)) < 0.85
+            want = oracle.process_voxel_grid(g, m, 90)
+            for knob in (0, 4):
+                pb3d_gpu._lib.set_tuning("misc2", knob)
+                try:
+                    got = pb3d_gpu.process_voxel_grid(g, m, 90)
+                finally:
+                    pb3d_gpu._lib.set_tuning("misc2", 0)
+                assert np.array_equal(got, want), (W, H, D, kind, knob, int((got != want).sum()))
