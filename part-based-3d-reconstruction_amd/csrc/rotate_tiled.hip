@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colo
             const u32 f = (u32)(128 * s) + (u32)(127 - lr);
             const u32 y = pb3d_div(f, mD), z = f - y * mD.d;
             const i64 n0 = (i64)c0 - (i64)z;
-            const bool ok = live && cmode && n0 >= 0 && n0 < W;
+            const bool ok = live && (i64)f < HD && cmode && n0 >= 0 && n0 < W;      // (f >= H * D: the ragged last segment of a stream that is not whole lines)
             const i64 v0s = (n0 * H + (i64)y) * D + scol;                  // first source voxel of the piece
             const bool whole = cmode == 2 || (v0s >= 0 && v0s + 16 <= nvox_all);
             const u8* sp8 = colored + v0s * 3;
@@ -1053,19 +1053,20 @@ __global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colo
         }
         if (tid < 128) {                                                   // job bits of the source pixel of local row tid
             const u32 f = (u32)(128 * s) + (u32)(127 - tid);
-            const u32 y = live ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+            const bool fin = live && (i64)f < HD;
+            const u32 y = fin ? pb3d_div(f, mD) : 0u, z = fin ? f - y * mD.d : 0u;
             const i64 n0 = (i64)c0 - (i64)z;
-            stg_a = (live && n0 >= 0 && n0 < W) ? A[n0 * H + (i64)y] : 0u;
+            stg_a = (fin && n0 >= 0 && n0 < W) ? A[n0 * H + (i64)y] : 0u;
         }
         const u32 f = (u32)(128 * s) + (u32)(16 * zg);
         const bool pin = live && (i64)f < HD;                               // this thread's piece lies inside the stream (H * D % 16 == 0: whole or absent)
-        const u32 y = pin ? pb3d_div(f, mD) : 0u, z = f - y * mD.d;
+        const u32 y = pin ? pb3d_div(f, mD) : 0u, z = pin ? f - y * mD.d : 0u;
         stg_nA = (i64)z + 16 <= D ? 16 : (int)(D - (i64)z);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const i64 x = x0 + 4 * xg + i;
             u32 bits = 0, da = 0, db = 0;
-            if (live && x < W) {
+            if (pin && x < W) {
                 bits = vwin(x, (i64)z);
                 if (stg_nA < 16) bits |= vwin(x, (i64)z - D);
                 if (bits) { da = A[x * H + (i64)y]; if (stg_nA < 16) db = A[x * H + (i64)y + 1]; }
@@ -1123,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colo
                 const int wi = v0 >> 4;
                 const u32 win = (u32)kb[wi] | ((wi < 7 ? (u32)kb[wi + 1] : 0u) << 16);
                 const u32 kb6 = (win >> (v0 & 15)) & 0x3fu;
+                if ((128 * s) * 3 + 16 * pc >= HD * 3) continue;                     // (a piece past the stream's end: ragged last segment only)
                 u32x4 val = (u32x4)(0u);
                 if (kb6) {
                     const u32x4 src = *(const u32x4*)(colored + rowoff + 16 * pc);
@@ -1357,9 +1359,11 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
                        (u32*)A);
     PB3D_CHECK_LAUNCH();
     if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
-    if (rgbsrc && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && H * D < (1ll << 31) && ctx->tune_misc[2] != 2 &&
-        ((((uintptr_t)d_colored) | ((uintptr_t)d_out)) & 15u) == 0) {            // rows that are not whole lines: the (y, z) stream of every x-row in whole lines
-        const i64 nseg = H * D / 128, nxt = (W + 127) / 128;
+    // rows that are not whole lines: the (y, z) stream of every x-row in whole lines (H * D % 128 == 0) or, round 3, in whole 16-byte pieces
+    // with a ragged last segment (H * D % 16 == 0; tune misc2 = 4: lines only)
+    if (rgbsrc && D % 128 != 0 && ((H * D) % 128 == 0 || ((H * D) % 16 == 0 && ctx->tune_misc[2] != 4)) && D >= 128 && H * D < (1ll << 31) - 256 &&
+        ctx->tune_misc[2] != 2 && ((((uintptr_t)d_colored) | ((uintptr_t)d_out)) & 15u) == 0) {
+        const i64 nseg = (H * D + 127) / 128, nxt = (W + 127) / 128;
         const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
         const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
         hipLaunchKernelGGL(k_part90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_colored, (const u32*)A, (const u32*)bits, nw, pm.c0, pm.c2, W,

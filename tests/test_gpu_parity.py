@@ -1502,3 +1502,17 @@ def test_rot90_flat_ragged_streams(pb3d_gpu, oracle):
                 finally:
                     pb3d_gpu._lib.set_tuning("misc2", 0)
                 assert np.array_equal(got, want), (W, H, D, kind, knob, int((got != want).sum()))
+    # the same streams through the six-job part_carve sweep (k_part90_flat)
+    pal = np.array(list(pb3d_gpu.PART_COLORS.values()), np.uint8)
+    for (W, H, D) in [(200, 12, 204), (150, 24, 202), (131, 4, 140)]:
+        lab = rng.integers(1, len(pal), (H // 4 + 1, W // 4 + 1)).repeat(4, 0).repeat(4, 1)[:H, :W]
+        sem = pal[lab]
+        col = pal[rng.integers(1, len(pal), (W, H, D))] * (rng.random((W, H, D, 1)) < 0.6).astype(np.uint8)
+        want = oracle.part_carve(col, sem, JOBS_NB1)
+        for knob in (0, 4):
+            pb3d_gpu._lib.set_tuning("misc2", knob)
+            try:
+                got = pb3d_gpu.part_carve(col, sem, JOBS_NB1)
+            finally:
+                pb3d_gpu._lib.set_tuning("misc2", 0)
+            assert np.array_equal(got, want), (W, H, D, knob, int((got != want).any(-1).sum()))
