@@ -353,16 +353,22 @@ __global__ __launch_bounds__(STHREADS, 4) void k_s32_step(const u32* __restrict_
     const int tz = tid & 15, jr = tid >> 4;
     const i64 zc = z0 + 4 * tz;
     const bool zok = zc < Dp;
-    for (int g = g_beg; g < g_end; ++g) {
+    // the footprint of plane group g + 1 is in flight (in registers) while group g is evaluated: written into LDS one group at a time, the
+    // load -> barrier -> evaluate -> store sequence left the waves waiting 68 % of their cycles (profiles/r03_sliced_chain_sq_counters.txt)
+    u32x4 v[SMAXU];
+    auto load_group = [&](int g) {
         const u32* src = in + (i64)g * W * Dp;
-        u32x4 v[SMAXU];
 #pragma unroll
         for (int j = 0; j < SMAXU; ++j)
             if (ug[j] != 0xffffffffu) v[j] = *(const u32x4*)(src + ug[j]);
+    };
+    load_group(g_beg);
+    for (int g = g_beg; g < g_end; ++g) {
 #pragma unroll
         for (int j = 0; j < SMAXU; ++j)
             if (ug[j] != 0xffffffffu) { u32* d = tile + ul[j]; d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w; }
         __syncthreads();
+        if (g + 1 < g_end) load_group(g + 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32 R[4];
