@@ -38,6 +38,7 @@ struct pb3d_ctx {
     int tune_sliced;            // PB3D_SLICED: 0 = chains of >= 2 rotation steps run bit-sliced (csrc/sliced.hip), 1 = never, 2 = also single steps
     int tune_rot90_wide;        // PB3D_ROT90_WIDE: 1 = the 256 x 256-tile form of the 90-degree step (development A/B)
     bool rot90w_lds_set;
+    bool rot90wf_lds_set;       // ... and for its form on the rows' (y, z) streams (odd row lengths)
     int tune_s32_gpw;           // PB3D_S32_GPW: plane groups per workgroup of the sliced step kernel (0 = choose)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).

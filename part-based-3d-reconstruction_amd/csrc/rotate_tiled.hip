@@ -137,6 +137,22 @@ __global__ __launch_bounds__(256) void k_rot_valid(RotParams p, i64 W, i64 D, in
     }
 }
 
+// Per x-row: is its set of valid z an interval?  lo | hi << 16 for [lo, hi) (empty: 0), 0xffffffff otherwise (a kernel then reads
+// the bits).  The bounds tests are linear in z for a fixed x, so every row of a 90-degree step is one; the check costs nothing.
+__global__ __launch_bounds__(256) void k_rot_ivals(const u32* __restrict__ bits, i64 W, i64 D, int nw, u32* __restrict__ ivals) {
+    const i64 x = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    int first = -1, last = -1, cnt = 0;
+    for (int w = 0; w < nw; ++w) {
+        const u32 v = bits[x * nw + w];
+        if (!v) continue;
+        if (first < 0) first = 32 * w + __ffs((int)v) - 1;
+        last = 32 * w + 31 - __clz((int)v);
+        cnt += __popc(v);
+    }
+    ivals[x] = cnt == 0 ? 0u : (cnt == last - first + 1 && last < 65535) ? (u32)first | ((u32)(last + 1) << 16) : 0xffffffffu;
+}
+
 // Workgroup -> (z tile, x tile, plane chunk).  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels one), each with
 // its own L2.  On grids whose rows are not multiples of 128 bytes every tile row straddles two lines on both sides: the other half
 // of a written line belongs to the z-neighbour tile (or the next plane's first tile), the other half of a read line to the
@@ -565,8 +581,8 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_rot90w(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                  const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
-                                                 i64 W, i64 H, i64 D, int TY, TileMap tm) {
-    extern __shared__ __attribute__((aligned(16))) u8 wtile[];          // 256 rows x 256 bytes
+                                                 i64 W, i64 H, i64 D, int TY, TileMap tm, int blk_on) {
+    extern __shared__ __attribute__((aligned(16))) u8 wtile[];          // 256 rows x 256 bytes, then the workgroup's mask flags
     const int tid = threadIdx.x;
     i64 zt, xt, yc;
     if (!tile_of_block(tm, &zt, &xt, &yc)) return;
@@ -589,29 +605,69 @@ __global__ __launch_bounds__(1024) void k_rot90w(const u8* __restrict__ in, u8* 
         if (x < W && zo < D) { const u32* vr = vbits + x * nw + (zo >> 5); v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zo & 31)) & 0xffffu; }
         vb[i] = v;
     }
+    // The workgroup's mask flags (blk_on): its 256 source rows and 256 output rows are the same for all of its planes, and the mask
+    // bytes of one row's planes are neighbours in memory -- fetched once, eight planes per load, kept as 0 / 1 flags behind the tile:
+    // flag of plane y_beg + p at blk[512 p + r], r < 256 a source row, 256 + r an output row.  (Per plane, every thread fetched the
+    // bytes of its four source rows and four output rows: 8 more memory instructions per thread, each byte a 64-byte line of its own.)
+    u8* blk = wtile + 256 * 256;
+    if (blk_on) {
+        if (tid < 512) {
+            const bool src = tid < 256;
+            const i64 row = src ? rbase0 + tid : x0 + (tid - 256);
+            const u8* mp = src ? mask_src : mask_dst;
+            const bool rok = row >= 0 && row < W;
+            for (i64 y = y_beg; y < y_end; y += 8) {
+                u32 lo = 0, hi = 0;
+                if (rok) {
+                    if (!mp) { lo = 0x01010101u; hi = 0x01010101u; }
+                    else if (y + 8 <= H) { lo = *(const u32_u*)(mp + row * H + y); hi = *(const u32_u*)(mp + row * H + y + 4); }
+                    else
+                        for (int b = 0; b < 8 && y + b < H; ++b) { const u32 v = mp[row * H + y + b]; if (b < 4) lo |= v << (8 * b); else hi |= v << (8 * (b - 4)); }
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (y + b < y_end) blk[512 * (y + b - y_beg) + tid] = (u8)((((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu) != 0);
+            }
+        }
+        __syncthreads();
+    }
     u32x4 stg[4];
-    u32 msk;
+    u32 ms_raw, md_raw;       // the mask bytes as loaded (byte j: source row j, byte i: output row i): a prefetch only ISSUES loads --
+                              // looking at a mask byte here would wait for it, and with it (the counter is in order) for the plane's data
     auto load_plane = [&](i64 y) {
-        u32 mk = 0;
+        u32 a = 0, b = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase0 + (tid >> 4) + 64 * j;
             stg[j] = (u32x4)(0u);
             if (y < y_end && col_ok && n0 >= 0 && n0 < W) {
                 stg[j] = __builtin_nontemporal_load((const u32x4*)(in + (n0 * H + y) * D + scol));
-                mk |= (u32)((mask_src ? mask_src[n0 * H + y] : (u8)1) != 0) << j;
+                if (!blk_on) a |= (mask_src ? (u32)mask_src[n0 * H + y] : 1u) << (8 * j);
             }
         }
+        if (!blk_on) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 x = x0 + 4 * xg + i;
-            if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
+            for (int i = 0; i < 4; ++i) {
+                const i64 x = x0 + 4 * xg + i;
+                if (y < y_end && x < W && vb[i]) b |= (mask_dst ? (u32)mask_dst[x * H + y] : 1u) << (8 * i);
+            }
         }
-        msk = mk;
+        ms_raw = a; md_raw = b;
     };
     load_plane(y_beg);
     for (i64 y = y_beg; y < y_end; ++y) {
-        const u32 mkc = msk;
+        u32 mkc = 0;
+        if (blk_on) {
+            const u8* bp = blk + 512 * (y - y_beg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mkc |= (u32)bp[(tid >> 4) + 64 * j] << j;
+            const u32 md = *(const u32*)(bp + 256 + 4 * xg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mkc |= (vb[i] ? ((md >> (8 * i)) & 1u) : 0u) << (4 + i);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mkc |= (u32)(((ms_raw >> (8 * j)) & 0xffu) != 0) << j | (u32)(((md_raw >> (8 * j)) & 0xffu) != 0) << (4 + j);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lr = (tid >> 4) + 64 * j;
@@ -793,6 +849,241 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90_flat(const u8* __res
             }
             if (128 * s + 16 * zg < HD)                                                       // (absent only in a ragged last segment)
                 __builtin_nontemporal_store(r, (u32x4*)(out + x * HD + 128 * s + 16 * zg));     // a whole aligned piece (of a whole aligned line when H * D % 128 == 0)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2' with k_rot90w's workgroup (round 3): k_rot90_flat's tiling of the x-rows' (y, z) streams, 1024 threads, one 64 KB tile in LDS.
+// A tile is XW = 16 npc x-rows (W split evenly over ceil(W / 256) tiles: 355 -> 2 x 192, so a ragged W does not leave one tile
+// mostly empty) x one 256-byte segment of the stream; local source row lr holds byte j = 255 - lr of the segment.
+// Nothing in the prefetch may WAIT: tools/kbench6.hip (this data movement without masks) runs 355 x 512 x 355 in 34 us where the
+// first form of this kernel took 50 -- its prefetch looked a validity window up and then, depending on it, the destination mask,
+// two dependent round trips inside what should only issue loads (the wait for the first also waits for the segment's data: the
+// counter is in order).  Here the validity of an x-row is an INTERVAL of z (k_rot_ivals, cached with the bit table; the rows are
+// fixed for the workgroup's life, so it sits in registers), and the prefetch keeps the mask bytes raw: they are looked at where
+// the segment is consumed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 bits_between(int lo, int hi) {       // bits q in [0, 16) with lo <= q < hi
+    lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+    hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+    return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+}
+__global__ __launch_bounds__(1024) void k_rot90wf(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
+                                                  const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, const u32* __restrict__ ivals,
+                                                  int nw, int c0, int c2, i64 W, i64 H, i64 D, int TS, TileMap tm, pb3d_magic mD, i64 nseg, int npc, int blk_on) {
+    extern __shared__ __attribute__((aligned(16))) u8 wtile[];          // 256 local rows x 256 bytes, then the workgroup's mask block
+    __shared__ __attribute__((aligned(16))) u8 msh[1024];               // mask flags (0 / 1) of the segment: [0, 256) source rows, 256 + 256 p + r: output row r, plane ya + p
+    const int tid = threadIdx.x;
+    i64 zt, xt, sc;
+    if (!tile_of_block(tm, &zt, &xt, &sc)) return;                          // whole workgroup, before any barrier
+    const int XW = 16 * npc;
+    const i64 x0 = xt * XW;
+    const i64 s_beg = sc * TS;
+    const i64 s_end = s_beg + TS < nseg ? s_beg + TS : nseg;
+    const i64 HD = H * D;
+    const int cb = tid & 15;
+    const i64 scol = x0 + c2 + 16 * cb;                 // source column of this thread's block
+    const int cmode = 16 * cb >= XW ? 0 : (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
+    const int zg = tid & 15, xg = tid >> 4;
+    const int g = 15 - zg;
+    const u32 rd_off = (u32)(16 * g * 256 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
+    const bool xrow_ok = 4 * xg < XW;                   // (XW is a multiple of 16: a group of 4 rows is inside the tile or outside)
+    const int mgrp = tid >> 8, mrow = tid & 255;        // mask role: group 0 = source row mrow, group p + 1 = output row mrow at plane ya + p
+    u32 iv[4];                                          // valid z of this thread's output rows: lo | hi << 16; 0xffffffff: not an interval, use the bits
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 x = x0 + 4 * xg + i;
+        iv[i] = (xrow_ok && x < W) ? ivals[x] : 0u;
+    }
+    auto vwin = [&](i64 x, i64 zlo) -> u32 {
+        if (zlo <= -16 || zlo >= D) return 0u;
+        const i64 zs = zlo < 0 ? 0 : zlo;
+        const u32* vr = vbits + x * nw + (zs >> 5);
+        u32 v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zs & 31)) & 0xffffu;
+        if (zlo < 0) v = (v << (int)(-zlo)) & 0xffffu;
+        return v;
+    };
+    // The workgroup's MASK BLOCK: its segments lie in the planes Y0 .. Y1 (a handful: TS * 256 / D), and of the two mask images they
+    // touch only the pixels (any source row, those planes) and (the tile's XW output rows, those planes).  Those bytes are fetched
+    // ONCE, eight planes of a row per load (they are neighbours in memory), and stay in LDS behind the tile: row r of window w at
+    // blk + (w * R + r) * 8, rows [0, W) = mask_src's, W + i = mask_dst's row x0 + i.  Fetched per segment instead, every byte was
+    // one 64-byte line through the L1 that the segment's own 64 KB had just emptied -- as much line traffic again as the data
+    // (355 x 512 x 355: 44.7 us, 37.7 without masks).  blk_on = 0 (the block would not fit): the bytes come from memory per segment.
+    u8* blk = wtile + 256 * 256;
+    const u32 Y0 = pb3d_div((u32)(256 * s_beg), mD);
+    const i64 flast = (256 * s_end < HD ? 256 * s_end : HD) - 1;
+    const u32 Y1 = pb3d_div((u32)flast, mD);
+    const int R = (int)W + XW;
+    auto fill_block = [&]() {
+        const int nwin = (int)(Y1 - Y0) / 8 + 1;
+        for (int r = tid; r < R; r += 1024) {
+            const bool src = r < W;
+            const i64 row = src ? r : x0 + (r - W);
+            const u8* mp = src ? mask_src : mask_dst;
+            for (int w = 0; w < nwin; ++w) {
+                const i64 y = (i64)Y0 + 8 * w;
+                u32 lo = 0, hi = 0;
+                if (row < W) {
+                    if (!mp) { lo = 0x01010101u; hi = 0x01010101u; }
+                    else if (y + 8 <= H) { lo = *(const u32_u*)(mp + row * H + y); hi = *(const u32_u*)(mp + row * H + y + 4); }
+                    else
+                        for (int b = 0; b < 8 && y + b < H; ++b) { const u32 v = mp[row * H + y + b]; if (b < 4) lo |= v << (8 * b); else hi |= v << (8 * (b - 4)); }
+                }
+                *(u32*)(blk + ((i64)w * R + r) * 8) = lo;
+                *(u32*)(blk + ((i64)w * R + r) * 8 + 4) = hi;
+            }
+        }
+    };
+    // The loop is software-pipelined by hand: a workgroup is alone on its CU, so whatever stands between "the segment's data has
+    // arrived" and "the next segment's loads are issued" is paid in full.  The ADDRESSES of segment s + 2 are computed (the
+    // divisions, the bounds tests) while the loads of s + 1 are in flight, the loads of s + 1 are issued right behind the barrier that
+    // frees the registers, and the keep bits of s are formed behind them.
+    // The masks: a segment needs one byte per source row and one per output row and plane (a 256-byte segment touches at most three
+    // planes, D >= 128) -- 1024 bytes, one per THREAD, handed round through LDS as 0 / 1 flags.  (Every thread fetching the bytes of
+    // its own four source rows and four output rows was 8 - 12 more memory instructions per thread and segment, each a full pass of
+    // the address unit whatever it carries: 9 us of a 47 us launch at 355 x 512 x 355.)
+    u32 moff[4];           // pixel n0 * H + y of local row j's source row (its data start at moff * D + scol); ~0: absent
+    u32 mmoff;             // this thread's mask byte: offset into mask_src (group 0) / mask_dst; ~0: absent (flag 0)
+    int az; u32 ay;        // the output piece's first byte: z (-1: absent) and plane
+    u32 aya;               // plane of the segment's first byte
+    auto addr_seg = [&](i64 s) {
+        const bool live = s < s_end;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 4) + 64 * j;
+            const u32 f = (u32)(256 * s) + (u32)(255 - lr);
+            const u32 y = pb3d_div(f, mD), z = f - y * mD.d;
+            const i64 n0 = (i64)c0 - (i64)z;
+            const bool ok = live && (i64)f < HD && cmode != 0 && n0 >= 0 && n0 < W;
+            moff[j] = ok ? (u32)(n0 * H + (i64)y) : 0xffffffffu;
+        }
+        const u32 f = (u32)(256 * s) + (u32)(16 * zg);
+        const bool pin = live && xrow_ok && (i64)f < HD;
+        const u32 y = pin ? pb3d_div(f, mD) : 0u;
+        az = pin ? (int)(f - y * mD.d) : -1; ay = y;
+        aya = pb3d_div((u32)(256 * s), mD);
+        {
+            const u32 fm = (u32)(256 * s) + (mgrp == 0 ? (u32)(255 - mrow) : 0u);
+            const u32 ym = pb3d_div(fm, mD), zm = fm - ym * mD.d;
+            const i64 n0 = (i64)c0 - (i64)zm, x = x0 + mrow, yp = (i64)ym + mgrp - 1;
+            const bool ok = live && (mgrp == 0 ? ((i64)fm < HD && n0 >= 0 && n0 < W) : (mrow < XW && x < W && yp <= (i64)Y1));
+            if (blk_on) {
+                const i64 yq = (mgrp == 0 ? (i64)ym : yp) - (i64)Y0, r = mgrp == 0 ? n0 : W + mrow;
+                mmoff = ok ? (u32)(((yq >> 3) * R + r) * 8 + (yq & 7)) : 0xffffffffu;
+            } else mmoff = ok ? (u32)(mgrp == 0 ? n0 * H + (i64)ym : x * H + yp) : 0xffffffffu;
+        }
+    };
+    u32x4 stg[4];
+    u32 mraw;              // this thread's mask byte, as loaded (0x100: no mask, all set)
+    int pz; u32 py, pya;   // az, ay, aya of the segment in flight
+    auto issue_seg = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            stg[j] = (u32x4)(0u);
+            if (moff[j] != 0xffffffffu) {
+                const i64 doff = (i64)moff[j] * D + scol;
+                const u8* sp = in + doff;
+                // a ragged block may be read whole as long as it stays inside the volume: the bytes beyond the row belong to the
+                // neighbouring row and are dropped by the validity bits (their source column is outside [0, D))
+                if (cmode == 2 || (doff >= 0 && doff + 16 <= W * HD)) stg[j] = __builtin_nontemporal_load((const u32x4_u*)sp);
+                else {                                                     // the ragged block of the last tile: byte by byte inside [0, D)
+                    u32 t4[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; ++b)
+                        if (scol + b >= 0 && scol + b < D) t4[b >> 2] |= (u32)sp[b] << (8 * (b & 3));
+                    stg[j].x = t4[0]; stg[j].y = t4[1]; stg[j].z = t4[2]; stg[j].w = t4[3];
+                }
+            }
+        }
+        if (!blk_on) {
+            const u8* mp = mgrp == 0 ? mask_src : mask_dst;
+            mraw = mmoff == 0xffffffffu ? 0u : (mp ? (u32)mp[mmoff] : 0x100u);
+        }
+        pz = az; py = ay; pya = aya;
+    };
+    auto issue_mask = [&]() { if (blk_on) mraw = mmoff == 0xffffffffu ? 0u : (u32)blk[mmoff]; };
+    if (blk_on) { fill_block(); __syncthreads(); }
+    addr_seg(s_beg);
+    issue_seg();
+    issue_mask();
+    addr_seg(s_beg + 1);
+    for (i64 s = s_beg; s < s_end; ++s) {
+        // ---- the segment's data has arrived: into LDS, with the mask flags
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = (tid >> 4) + 64 * j;
+            *(u32x4*)(wtile + lr * 256 + 16 * (cb ^ ((lr >> 4) & 15))) = stg[j];
+        }
+        msh[tid] = (u8)(mraw != 0);
+        const int z = pz;
+        const int pa = (int)(py - pya);                   // the piece's plane within the segment's (0 .. 2)
+        __syncthreads();
+        issue_seg();                                      // segment s + 1 (addresses ready)
+        issue_mask();
+        // ---- keep bits of this thread's four output pieces of segment s: validity, destination rows' masks, source rows' masks
+        u32 kcur[4];
+        {
+            const int nA = z + 16 <= (int)D ? 16 : (int)D - z;
+            const u32 lowA = (1u << nA) - 1u;
+            const u32x4 sm = *(const u32x4*)(msh + 16 * g);               // flags of source rows 16 g .. 16 g + 15; byte q of the piece comes from row 16 g + 15 - q
+            const u32 asc = (((sm.x & 0x01010101u) * 0x01020408u) >> 24) | ((((sm.y & 0x01010101u) * 0x01020408u) >> 24) << 4) |
+                            ((((sm.z & 0x01010101u) * 0x01020408u) >> 24) << 8) | ((((sm.w & 0x01010101u) * 0x01020408u) >> 24) << 12);
+            const u32 srcbits = __brev(asc) >> 16;
+            const u32 mdA = z >= 0 ? *(const u32*)(msh + 256 + 256 * pa + 4 * xg) : 0u;
+            const u32 mdB = (z >= 0 && nA < 16) ? *(const u32*)(msh + 256 + 256 * (pa + 1) + 4 * xg) : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32 k = 0;
+                if (z >= 0) {
+                    u32 bits;
+                    if (iv[i] != 0xffffffffu) {
+                        const int lo = (int)(iv[i] & 0xffffu), hi = (int)(iv[i] >> 16);
+                        bits = (bits_between(lo - z, hi - z) & lowA) | (bits_between(lo - (z - (int)D), hi - (z - (int)D)) & ~lowA & 0xffffu);
+                    } else { bits = vwin(x0 + 4 * xg + i, (i64)z); if (nA < 16) bits |= vwin(x0 + 4 * xg + i, (i64)z - D); }
+                    const u32 mA = ((mdA >> (8 * i)) & 0xffu) ? lowA : 0u;
+                    const u32 mB = ((mdB >> (8 * i)) & 0xffu) ? (0xffffu & ~lowA) : 0u;
+                    k = bits & (mA | mB) & srcbits;
+                }
+                kcur[i] = k;
+            }
+        }
+        u32 d[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(wtile + rd_off + rr * 256);
+        __syncthreads();                                  // the tile and the flags are free again: the next segment's may be written
+        addr_seg(s + 2);
+        if (!xrow_ok || z < 0) continue;                                   // (a piece past the stream's end: ragged last segment only)
+        u32 o[4][4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 A = d[15 - 4 * w], B = d[14 - 4 * w], Cc = d[13 - 4 * w], E = d[12 - 4 * w];
+            const u32 t0 = perm(B, A, 0x05010400u), t1 = perm(B, A, 0x07030602u);
+            const u32 u0 = perm(E, Cc, 0x05010400u), u1 = perm(E, Cc, 0x07030602u);
+            o[0][w] = perm(u0, t0, 0x05040100u);
+            o[1][w] = perm(u0, t0, 0x07060302u);
+            o[2][w] = perm(u1, t1, 0x05040100u);
+            o[3][w] = perm(u1, t1, 0x07060302u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i64 x = x0 + 4 * xg + i;
+            if (x >= W) continue;
+            const u32 kb = kcur[i];
+            u32x4 r = (u32x4)(0u);
+            if (kb) {
+                r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
+                if (kb != 0xffffu) {
+                    u32 mw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 b4 = (kb >> (4 * w)) & 0xfu;
+                        mw[w] = ((b4 & 1u) ? 0x000000ffu : 0u) | ((b4 & 2u) ? 0x0000ff00u : 0u) | ((b4 & 4u) ? 0x00ff0000u : 0u) |
+                                ((b4 & 8u) ? 0xff000000u : 0u);
+                    }
+                    r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
+                }
+            }
+            __builtin_nontemporal_store(r, (u32x4*)(out + x * HD + 256 * s + 16 * zg));
         }
     }
 }
@@ -1200,7 +1491,7 @@ static PermMap perm_map(const double M[9], const double off[3]) {
 static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u32** bits, int* nw) {
     const int n = (int)(((D + 63) / 64) * 2 + 2);
     void* buf;
-    PB3D_TRY(pb3d_scratch(ctx, 10, (size_t)W * n * sizeof(u32), &buf));
+    PB3D_TRY(pb3d_scratch(ctx, 10, (size_t)W * (n + 1) * sizeof(u32), &buf));           // + one interval word per row (pb3d_valid_ivals)
     // the table depends on (matrix, offset, W, D) only and slot 10 is private to it: a repeated step (every 90-degree call on one shape)
     // finds it in place -- at 512-class sizes the memset + table kernel were 10 % of a process_voxel_grid(., ., 90) call
     pb3d_ctx::ValidCache& vc = ctx->valid_cache;
@@ -1212,6 +1503,8 @@ static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u3
     PB3D_HIP(hipMemsetAsync(buf, 0, (size_t)W * n * sizeof(u32), ctx->stream));
     dim3 grid((unsigned)((D + 255) / 256), (unsigned)W);
     hipLaunchKernelGGL(k_rot_valid, grid, dim3(256), 0, ctx->stream, p, W, D, n, (u32*)buf);
+    PB3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_rot_ivals, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, ctx->stream, (const u32*)buf, W, D, n, (u32*)buf + W * n);
     PB3D_CHECK_LAUNCH();
     vc.buf = buf; vc.gen = ctx->scratch_gen; vc.W = W; vc.D = D;
     static_assert(sizeof(vc.p) == sizeof(RotParams), "ValidCache holds one RotParams");
@@ -1250,6 +1543,27 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
             PB3D_REQUIRE(D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_out) & 15u) == 0, "pb3d_rotate_perm: colour output needs D %% 16 == 0");
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm, d_rgb_hw3);
+        } else if (flat && W >= 160 && H * D < (1ll << 31) - 1024 && W * H < 0xffffffffll && ctx->tune_rot90_wide != 2) {
+            // 256-byte segments, 1024 threads (tune rot90_wide = 2: the 128-row x 128-byte form below)
+            if (!ctx->rot90wf_lds_set) {
+                PB3D_HIP(hipFuncSetAttribute((const void*)k_rot90wf, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256 + 48 * 1024));
+                ctx->rot90wf_lds_set = true;
+            }
+            const i64 nx0 = (W + 255) / 256;
+            const int npc = (int)((((W + nx0 - 1) / nx0) + 15) / 16);          // 16-byte blocks of a tile's source rows (10 .. 16)
+            const i64 nseg = (H * D + 255) / 256, nxt = (W + 16 * npc - 1) / (16 * npc);
+            // workgroups per CU: as many (up to 4) as leave a workgroup at least 8 segments (fewer, longer workgroups win at these sizes)
+            int fillw = ctx->tune_misc[1] > 0 ? ctx->tune_misc[1] : 4;
+            if (ctx->tune_misc[1] <= 0)
+                while (fillw > 1 && planes_per_chunk(nseg, nxt, ctx->cus, 32, fillw) < 8) fillw >>= 1;
+            const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, fillw);
+            const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), 0};
+            // the workgroup's mask block behind the tile: (W + XW) rows x 8 planes per window, windows for the planes TS segments span
+            const i64 nwin = ((i64)TS * 256 / D + 2) / 8 + 1;
+            const size_t blk_bytes = (size_t)((W + 16 * npc) * 8 * nwin);
+            const int blk_on = blk_bytes <= 48 * 1024 && ctx->tune_misc[5] != 16;
+            hipLaunchKernelGGL(k_rot90wf, dim3(tilemap_blocks(fm)), dim3(1024), 256 * 256 + (blk_on ? blk_bytes : 0), ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
+                               (const u32*)bits, (const u32*)bits + W * nw, nw, pm.c0, pm.c2, W, H, D, TS, fm, pb3d_make_magic((u32)D), nseg, npc, blk_on);
         } else if (flat) {
             const i64 nseg = (H * D + 127) / 128, nxt = (W + 127) / 128;
             const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
@@ -1265,7 +1579,7 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
             // Workgroups per CU: as many (up to 4) as leave a workgroup at least 4 planes -- 1024^3 likes 4 (0.430; 2: 0.445),
             // 512^3 2 (0.061; 1: 0.075, 4: 0.068), 512 x 278 x 512 1 (0.035; 2: 0.041, 4: 0.045).
             if (!ctx->rot90w_lds_set) {
-                PB3D_HIP(hipFuncSetAttribute((const void*)k_rot90w, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256));
+                PB3D_HIP(hipFuncSetAttribute((const void*)k_rot90w, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256 + 512 * 64));
                 ctx->rot90w_lds_set = true;
             }
             const i64 wt = ((D + 255) / 256) * ((W + 255) / 256);
@@ -1274,8 +1588,9 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
                 while (fillw > 1 && planes_per_chunk(H, wt, ctx->cus, 32, fillw) < 4) fillw >>= 1;
             const int TYw = planes_per_chunk(H, wt, ctx->cus, 32, fillw);
             const TileMap wm = {(int)((D + 255) / 256), (int)((W + 255) / 256), (int)((H + TYw - 1) / TYw), 0};
-            hipLaunchKernelGGL(k_rot90w, dim3(tilemap_blocks(wm)), dim3(1024), 256 * 256, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
-                               pm.c0, pm.c2, W, H, D, TYw, wm);
+            const int blk_on = TYw <= 64 && ctx->tune_misc[5] != 16;                 // the workgroup's mask flags behind the tile: 512 bytes per plane
+            hipLaunchKernelGGL(k_rot90w, dim3(tilemap_blocks(wm)), dim3(1024), 256 * 256 + (blk_on ? 512 * TYw : 0), ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
+                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TYw, wm, blk_on);
         } else if (D % 16 == 0 && pm.c2 % 16 == 0)
             hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);

@@ -1495,13 +1495,25 @@ def test_rot90_flat_ragged_streams(pb3d_gpu, oracle):
             g = (rng.random((W, H, D)) < 0.5).astype(np.uint8) if kind == "binary" else rng.integers(0, 256, (W, H, D), dtype=np.uint8)
             m = rng.random((H, W)) < 0.85
             want = oracle.process_voxel_grid(g, m, 90)
-            for knob in (0, 4):
-                pb3d_gpu._lib.set_tuning("misc2", knob)
+            for knob, wide, misc5 in ((0, 0, 0), (0, 0, 16), (0, 2, 0), (4, 0, 0)):   # 256-byte segments (k_rot90wf; mask block on / off), 128-byte segments (k_rot90_flat), tile kernel
+                pb3d_gpu._lib.set_tuning("misc2", knob); pb3d_gpu._lib.set_tuning("rot90_wide", wide); pb3d_gpu._lib.set_tuning("misc5", misc5)
                 try:
                     got = pb3d_gpu.process_voxel_grid(g, m, 90)
                 finally:
-                    pb3d_gpu._lib.set_tuning("misc2", 0)
-                assert np.array_equal(got, want), (W, H, D, kind, knob, int((got != want).sum()))
+                    pb3d_gpu._lib.set_tuning("misc2", 0); pb3d_gpu._lib.set_tuning("rot90_wide", 0); pb3d_gpu._lib.set_tuning("misc5", 0)
+                assert np.array_equal(got, want), (W, H, D, kind, knob, wide, misc5, int((got != want).sum()))
+    # whole-line streams of odd row length (H * D % 128 == 0): both segment widths
+    for (W, H, D) in [(355, 128, 355), (259, 128, 259), (437, 128, 437), (180, 128, 182)]:
+        g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
+        m = rng.random((H, W)) < 0.85
+        want = oracle.process_voxel_grid(g, m, 90)
+        for wide, misc5 in ((0, 0), (0, 16), (2, 0)):          # masks from the workgroup's LDS block / fetched per segment; 128-byte segments
+            pb3d_gpu._lib.set_tuning("rot90_wide", wide); pb3d_gpu._lib.set_tuning("misc5", misc5)
+            try:
+                got = pb3d_gpu.process_voxel_grid(g, m, 90)
+            finally:
+                pb3d_gpu._lib.set_tuning("rot90_wide", 0); pb3d_gpu._lib.set_tuning("misc5", 0)
+            assert np.array_equal(got, want), (W, H, D, wide, misc5, int((got != want).sum()))
     # the same streams through the six-job part_carve sweep (k_part90_flat)
     pal = np.array(list(pb3d_gpu.PART_COLORS.values()), np.uint8)
     for (W, H, D) in [(200, 12, 204), (150, 24, 202), (131, 4, 140)]:

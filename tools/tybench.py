@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--wide", default="0", help="comma list of tune rot90_wide values to interleave with the fills (0 = the 256 x 256-tile kernel where it applies, 2 = the 128-tile kernel)")
+    ap.add_argument("--variants", default="", help="instead of fills x wide: ';'-separated tuning sets, each 'k=v,k=v' ('' = defaults), interleaved")
     a = ap.parse_args()
     rng = np.random.default_rng(5)
     for sh in a.shapes.split(","):
@@ -35,6 +36,20 @@ def main():
         d_occ = dev.DeviceBuffer(nvox); d_o = dev.DeviceBuffer(nvox); d_t = dev.DeviceBuffer(nvox)
         dev.synth_occ(0, W, H, D, 0, d_occ)
         res = {}
+        if a.variants:
+            sets = [dict(kv.split("=") for kv in v.split(",") if kv) for v in a.variants.split(";")]
+            keys = sorted({k for st in sets for k in st})
+            for r in range(a.rounds):
+                for v, st in zip(a.variants.split(";"), sets):
+                    for k in keys:
+                        pb3d._lib.set_tuning(k, int(st.get(k, 0)))
+                    res.setdefault(v or "default", []).append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t), a.reps), 4))
+            for k in keys:
+                pb3d._lib.set_tuning(k, 0)
+            print(json.dumps({"shape": [W, H, D], "ms_by_variant": res}), flush=True)
+            for b in (d_mwh, d_occ, d_o, d_t):
+                b.free()
+            continue
         for r in range(a.rounds):
             for wd in a.wide.split(","):
                 pb3d._lib.set_tuning("rot90_wide", int(wd))
