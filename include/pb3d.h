@@ -48,6 +48,11 @@ const char* pb3d_last_error(void);
 int pb3d_device_count(int* n);
 int pb3d_create(int device, pb3d_ctx** out);
 void pb3d_destroy(pb3d_ctx* ctx);
+/* A context belongs to ONE device; its stream, scratch and pools live there.  HIP's current device is a property of the host THREAD:
+ * pb3d_create makes `device` current for the calling thread, so "one thread (or one process) per GPU, each with its own context" needs
+ * nothing else.  A single thread that alternates between contexts of different devices calls pb3d_make_current(ctx) before each run of
+ * calls on that context (it is hipSetDevice(ctx's device); the entry points do not switch devices themselves). */
+int pb3d_make_current(pb3d_ctx* ctx);
 int pb3d_device_info(pb3d_ctx* ctx, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes);
 int pb3d_sync(pb3d_ctx* ctx);
 /* Development knobs (results never depend on them; they select between kernels that are all bit-exact).  Initial values come

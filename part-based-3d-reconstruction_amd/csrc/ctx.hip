@@ -128,6 +128,12 @@ int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     return PB3D_OK;
 }
 
+int pb3d_make_current(pb3d_ctx* ctx) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_make_current: null context");
+    PB3D_HIP(hipSetDevice(ctx->device));
+    return PB3D_OK;
+}
+
 void pb3d_destroy(pb3d_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "pb3d_device_count": [intp],
     "pb3d_create": [C.c_int, C.POINTER(vp)],
     "pb3d_destroy": [vp],
+    "pb3d_make_current": [vp],
     "pb3d_device_info": [vp, C.c_char_p, C.c_int, intp, i64p],
     "pb3d_sync": [vp],
     "pb3d_set_tuning": [vp, C.c_char_p, C.c_int],
