@@ -1456,6 +1456,47 @@ def test_rot90_wide_tile_kernel(pb3d_gpu, oracle):
                 assert np.array_equal(got, want), (W, H, D, kind, wide, int((got != want).sum()))
 
 
+def test_rot90_mask_blocks_random_shapes(pb3d_gpu, oracle):
+    """the 90-degree kernels that keep a workgroup's mask bytes / job bits in LDS (k_rot90w, k_rot90wf, k_part90), on seeded random
+    mid-size shapes: several 8-plane windows per workgroup, heights that end inside a window, W != D (a column offset), mask bytes
+    other than 0 / 1, empty mask rows -- block on and off (tune misc5 = 16), against the oracle."""
+    from pb3d import device as dev
+    rng = np.random.default_rng(77)
+    shapes = [(256, 37, 256), (512, 20, 256), (272, 19, 304), (355, 48, 355), (200, 36, 204), (300, 24, 250), (437, 16, 437), (161, 64, 161),
+              (384, 9, 384)]
+    for (W, H, D) in shapes:
+        g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
+        m = (rng.random((H, W)) < 0.8)
+        m[:, rng.integers(0, W, 7)] = False; m[rng.integers(0, H, 2), :] = False
+        want = oracle.process_voxel_grid(g, m, 90)
+        # the device entry takes the (W, H) byte image: any non-zero byte keeps
+        mb = np.ascontiguousarray(m.T).astype(np.uint8) * rng.integers(1, 256, (W, H), dtype=np.uint8)
+        d_g = dev.from_numpy(g); d_m = dev.from_numpy(mb); d_o = dev.DeviceBuffer(g.size); d_t = dev.DeviceBuffer(g.size)
+        for misc5 in (0, 16):
+            pb3d_gpu._lib.set_tuning("misc5", misc5)
+            try:
+                dev.process_grid(d_g, W, H, D, d_m, 90, d_o, d_t)
+                got = d_o.download((W, H, D))
+            finally:
+                pb3d_gpu._lib.set_tuning("misc5", 0)
+            assert np.array_equal(got, want), (W, H, D, misc5, int((got != want).sum()))
+        for b in (d_g, d_m, d_o, d_t):
+            b.free()
+    pal = np.array(list(pb3d_gpu.PART_COLORS.values()), np.uint8)
+    for (W, H, D) in [(256, 37, 256), (384, 21, 384), (304, 40, 304)]:
+        lab = rng.integers(1, len(pal), (H // 4 + 1, W // 4 + 1)).repeat(4, 0).repeat(4, 1)[:H, :W]
+        sem = pal[lab]
+        col = pal[rng.integers(1, len(pal), (W, H, D))] * (rng.random((W, H, D, 1)) < 0.6).astype(np.uint8)
+        want = oracle.part_carve(col, sem, JOBS_NB1)
+        for misc5 in (0, 16):
+            pb3d_gpu._lib.set_tuning("misc5", misc5)
+            try:
+                got = pb3d_gpu.part_carve(col, sem, JOBS_NB1)
+            finally:
+                pb3d_gpu._lib.set_tuning("misc5", 0)
+            assert np.array_equal(got, want), (W, H, D, misc5, int((got != want).any(-1).sum()))
+
+
 def test_recolour_entries_agree(pb3d_gpu, oracle):
     """pb3d_recolor_components_dev (scans the whole label volume) and pb3d_recolor_last_labelled_dev (walks the labelling's membership
     bits) write the same grid; the second refuses a label buffer that is not the last labelled one."""
