@@ -1599,14 +1599,15 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         else if (D % 16 == 0 && pm.c2 % 16 == 0 && W >= 256 && D >= 256 && ctx->tune_rot90_wide != 2 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0) {
             // the 256 x 256-tile form (tune rot90_wide = 2: the 128-tile kernel).  Measured with tools/tybench.py on one box, variants
             // interleaved (ms, 128-tile kernel -> this one): 1024^3 0.464 -> 0.430, 512^3 0.0665 -> 0.0608, 512 x 278 x 512 0.046 -> 0.035.
-            // Workgroups per CU: as many (up to 4) as leave a workgroup at least 4 planes -- 1024^3 likes 4 (0.430; 2: 0.445),
-            // 512^3 2 (0.061; 1: 0.075, 4: 0.068), 512 x 278 x 512 1 (0.035; 2: 0.041, 4: 0.045).
+            // Workgroups per CU: as many (up to 8) as leave a workgroup at least 4 planes.  With the mask flags in LDS (tools/tybench.py,
+            // fills interleaved, ms): 1024^3 likes 8 (0.421; 4: 0.439, 2: 0.446, 1: 0.447), 512^3 2 (0.053; 1: 0.077, 4: 0.056, 8: 0.063),
+            // 512 x 278 x 512 1 (0.029; 2 and more: 0.033).
             if (!ctx->rot90w_lds_set) {
                 PB3D_HIP(hipFuncSetAttribute((const void*)k_rot90w, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256 + 512 * 64));
                 ctx->rot90w_lds_set = true;
             }
             const i64 wt = ((D + 255) / 256) * ((W + 255) / 256);
-            int fillw = ctx->tune_misc[1] > 0 ? ctx->tune_misc[1] : 4;
+            int fillw = ctx->tune_misc[1] > 0 ? ctx->tune_misc[1] : 8;
             if (ctx->tune_misc[1] <= 0)
                 while (fillw > 1 && planes_per_chunk(H, wt, ctx->cus, 32, fillw) < 4) fillw >>= 1;
             const int TYw = planes_per_chunk(H, wt, ctx->cus, 32, fillw);

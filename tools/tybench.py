@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--wide", default="0", help="comma list of tune rot90_wide values to interleave with the fills (0 = the 256 x 256-tile kernel where it applies, 2 = the 128-tile kernel)")
+    ap.add_argument("--op", default="process", help="process: process_voxel_grid(occ, 90); part: part_carve with six 90-degree jobs (needs --variants)")
     ap.add_argument("--variants", default="", help="instead of fills x wide: ';'-separated tuning sets, each 'k=v,k=v' ('' = defaults), interleaved")
     a = ap.parse_args()
     rng = np.random.default_rng(5)
@@ -36,6 +37,18 @@ def main():
         d_occ = dev.DeviceBuffer(nvox); d_o = dev.DeviceBuffer(nvox); d_t = dev.DeviceBuffer(nvox)
         dev.synth_occ(0, W, H, D, 0, d_occ)
         res = {}
+        fn = lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t)
+        if a.op == "part":
+            import ctypes as C
+            m_hw = rng.random((H, W)) < 0.8
+            lab = rng.integers(0, 7, (W, H), dtype=np.uint8) * m_hw.T
+            msub = np.stack([(lab == j + 1).astype(np.uint8) for j in range(6)])
+            d_ms = dev.from_numpy(msub); d_col = dev.DeviceBuffer(nvox * 3); d_pout = dev.DeviceBuffer(nvox * 3)
+            dev.global_carve(dev.from_numpy(np.ascontiguousarray(m_hw).view(np.uint8)), dev.from_numpy(rng.integers(1, 255, (H, W, 3), dtype=np.uint8)), H, W, 90, d_col)
+            L, lib = pb3d._lib, pb3d._lib.load()
+            ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*([0] * 6))
+            fn = lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_ms.ptr), ang, skip, 6,
+                                                         C.c_void_p(d_pout.ptr)))
         if a.variants:
             sets = [dict(kv.split("=") for kv in v.split(",") if kv) for v in a.variants.split(";")]
             keys = sorted({k for st in sets for k in st})
@@ -43,7 +56,7 @@ def main():
                 for v, st in zip(a.variants.split(";"), sets):
                     for k in keys:
                         pb3d._lib.set_tuning(k, int(st.get(k, 0)))
-                    res.setdefault(v or "default", []).append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t), a.reps), 4))
+                    res.setdefault(v or "default", []).append(round(timeit(fn, a.reps), 4))
             for k in keys:
                 pb3d._lib.set_tuning(k, 0)
             print(json.dumps({"shape": [W, H, D], "ms_by_variant": res}), flush=True)
