@@ -18,6 +18,8 @@ python3 tools/opbench.py --size 512 --ops M3,M5,N2 > $O/opbench_512.jsonl 2>> $O
 echo "== sliced"; python3 tools/slicedbench.py > $O/slicedbench.jsonl 2> $O/slicedbench.err
 python3 tools/gcbench.py > $O/gcbench.jsonl 2> $O/gcbench.err
 python3 tools/tybench.py --shapes 1024x1024x1024,512x512x512,512x278x512,512x318x512 --fills 0,4,8 --wide 0,2 --rounds 3 > $O/tybench.jsonl 2> $O/tybench.err
+python3 tools/tybench.py --shapes 352x512x352,355x512x355,437x512x437,500x400x500,512x278x512,512x512x512,1024x1024x1024 --variants ";misc5=16;rot90_wide=2" --rounds 3 --reps 40 > $O/tybench_maskblock.jsonl 2>> $O/tybench.err
+python3 tools/tybench.py --op part --shapes 512x278x512,512x512x512,1024x1024x1024 --variants ";misc5=16" --rounds 3 --reps 15 > $O/tybench_part.jsonl 2>> $O/tybench.err
 python3 tools/shapebench.py > $O/shapebench.jsonl 2> $O/shapebench.err
 echo "== notebook 1"; python3 tools/notebook1_bench.py > $O/notebook1.json 2> $O/notebook1.err
 python3 tools/nb1stages.py > $O/nb1stages.json 2> $O/nb1stages.err
