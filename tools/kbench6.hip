@@ -42,14 +42,14 @@ __global__ __launch_bounds__(1024) void k_wf(const u8* __restrict__ in, u8* __re
     const i64 HD = H * D;
     const int cb = tid & 15;
     const i64 scol = x0 + 16 * cb;
-    const int cmode = 16 * cb >= XW ? 0 : (scol + 15 < D) ? 2 : (scol < D ? 1 : 0);
+    const int cmode = (VAR == 2 ? 16 * cb > XW : 16 * cb >= XW) ? 0 : (VAR == 2 || scol + 15 < D) ? 2 : (scol < D ? 1 : 0);
     const int zg = tid & 15, xg = tid >> 4;
     const int g = 15 - zg;
     const u32 rd_off = (u32)(16 * g * 256 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
     const bool xrow_ok = 4 * xg < XW;
     constexpr int DEPTH = VAR == 1 ? 2 : 1;
     u32x4 stg[DEPTH][4];
-    u32 ms_raw = 0, md_raw = 0; u8 mrow = 0;
+    u32 ms_raw = 0, md_raw = 0; u8 mrow = 0; u32 phs = 0;
     auto load_seg = [&](u32x4 (&st)[4], i64 s) {
         const bool live = s < s_end;
 #pragma unroll
@@ -63,22 +63,14 @@ __global__ __launch_bounds__(1024) void k_wf(const u8* __restrict__ in, u8* __re
             if (live && (i64)f < HD && cmode != 0 && n0 >= 0 && n0 < W) {
                 const u8* sp = in + (n0 * H + (i64)y) * D + scol;
                 if (VAR == 2) {
-                    // aligned blocks: lane cb loads block cb of the run that starts at the row's aligned-down address, lane 15's extra
-                    // block comes from a second (sparse) load; data shifted right by the row's phase
+                    // aligned blocks: lane cb loads block cb of the run that starts at the row's address rounded down to 16 (one lane more
+                    // than the row has blocks: npc <= 15), the neighbour's block comes by DPP (row_shl:1 within the 16 lanes of the row),
+                    // the bytes are shifted into place in registers
                     const u8* base = in + (n0 * H + (i64)y) * D + x0;
                     const u32 ph = (u32)((uintptr_t)base & 15u);
                     const u8* ap = base - ph + 16 * cb;
-                    u32x4 a = __builtin_nontemporal_load((const u32x4*)ap);
-                    u32x4 nb;
-                    nb.x = __shfl_down(a.x, 1, 16); nb.y = __shfl_down(a.y, 1, 16); nb.z = __shfl_down(a.z, 1, 16); nb.w = __shfl_down(a.w, 1, 16);
-                    if (cb == 15 || 16 * (cb + 1) >= XW) { if (ph) nb = __builtin_nontemporal_load((const u32x4*)(ap + 16)); }
-                    const u32 w8[8] = {a.x, a.y, a.z, a.w, nb.x, nb.y, nb.z, nb.w};
-                    const u32 dq = ph >> 2, bs = ph & 3;
-                    u32 r5[5];
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) r5[k] = dq == 0 ? w8[k] : dq == 1 ? w8[k + 1] : dq == 2 ? w8[k + 2] : w8[k + 3];
-                    st[j].x = __builtin_amdgcn_alignbyte(r5[1], r5[0], bs); st[j].y = __builtin_amdgcn_alignbyte(r5[2], r5[1], bs);
-                    st[j].z = __builtin_amdgcn_alignbyte(r5[3], r5[2], bs); st[j].w = __builtin_amdgcn_alignbyte(r5[4], r5[3], bs);
+                    st[j] = __builtin_nontemporal_load((const u32x4*)ap);       // raw: shifted where it is consumed
+                    phs |= ph << (4 * j);
                 } else if (cmode == 2 || sp + 16 <= in + W * HD) st[j] = __builtin_nontemporal_load((const u32x4_u*)sp);
                 if (VAR == 5) ms_raw |= (u32)mask[n0 * H + (i64)y] << (8 * j);
             }
@@ -112,9 +104,24 @@ __global__ __launch_bounds__(1024) void k_wf(const u8* __restrict__ in, u8* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lr = (tid >> 4) + 64 * j;
-            *(u32x4*)(wtile + lr * 256 + 16 * (cb ^ ((lr >> 4) & 15))) = (VAR == 5 && !((ms_raw >> (8 * j)) & 0xffu)) ? (u32x4)(0u) : cur[j];
+            u32x4 val = cur[j];
+            if (VAR == 2) {
+                const u32x4 a = cur[j];
+                u32x4 nb;
+                nb.x = (u32)__builtin_amdgcn_update_dpp(0, (int)a.x, 0x101, 0xf, 0xf, true); nb.y = (u32)__builtin_amdgcn_update_dpp(0, (int)a.y, 0x101, 0xf, 0xf, true);
+                nb.z = (u32)__builtin_amdgcn_update_dpp(0, (int)a.z, 0x101, 0xf, 0xf, true); nb.w = (u32)__builtin_amdgcn_update_dpp(0, (int)a.w, 0x101, 0xf, 0xf, true);
+                const u32 w8[8] = {a.x, a.y, a.z, a.w, nb.x, nb.y, nb.z, nb.w};
+                const u32 ph = (phs >> (4 * j)) & 15u, dq = ph >> 2, bs = ph & 3;
+                u32 r5[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) r5[k] = dq == 0 ? w8[k] : dq == 1 ? w8[k + 1] : dq == 2 ? w8[k + 2] : w8[k + 3];
+                val.x = __builtin_amdgcn_alignbyte(r5[1], r5[0], bs); val.y = __builtin_amdgcn_alignbyte(r5[2], r5[1], bs);
+                val.z = __builtin_amdgcn_alignbyte(r5[3], r5[2], bs); val.w = __builtin_amdgcn_alignbyte(r5[4], r5[3], bs);
+            }
+            if (16 * cb < XW || VAR != 2) *(u32x4*)(wtile + lr * 256 + 16 * (cb ^ ((lr >> 4) & 15))) = (VAR == 5 && !((ms_raw >> (8 * j)) & 0xffu)) ? (u32x4)(0u) : val;
         }
         u32 keepm = 0xf;
+        if (VAR == 2) phs = 0;
         if (VAR == 5) { keepm = 0; for (int i = 0; i < 4; ++i) keepm |= (u32)(((md_raw >> (8 * i)) & 0xffu) != 0) << i; ms_raw = 0; md_raw = 0; }
         if (VAR == 6 && tid < 512) msh[it & 1][tid] = mrow;
         __syncthreads();
