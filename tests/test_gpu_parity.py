@@ -1463,7 +1463,7 @@ def test_rot90_mask_blocks_random_shapes(pb3d_gpu, oracle):
     from pb3d import device as dev
     rng = np.random.default_rng(77)
     shapes = [(256, 37, 256), (512, 20, 256), (272, 19, 304), (355, 48, 355), (200, 36, 204), (300, 24, 250), (437, 16, 437), (161, 64, 161),
-              (384, 9, 384)]
+              (384, 9, 384), (600, 4, 600), (320, 2, 328), (161, 16, 129), (641, 16, 131), (1001, 16, 1001)]      # (three x-tiles; a segment over three planes; a large column offset)
     for (W, H, D) in shapes:
         g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         m = (rng.random((H, W)) < 0.8)
