@@ -110,6 +110,20 @@ int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_
 int pb3d_process_grid(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, int64_t D,
                       const uint8_t* mask_wh, int angle_interval, uint8_t* out);
 
+/* The same loop for grids that are NOT uint8.  The reference never looks at the dtype: scipy.ndimage.affine_transform(order=1) returns the
+ * dtype it was given and np.where(mask, grid, 0) keeps it (float16 and anything else SciPy's interpolation refuses: "data type not
+ * supported"; a bool grid becomes int64 in upstream's first np.where, so the host side passes it as PB3D_I64).  A plain
+ * kernel per step (csrc/rotate_typed.hip: f64 accumulation in SciPy's tap order, SciPy's store rule of the type, the step's carve in the
+ * same store); the notebooks only pass uint8, which keeps its own kernels above.  d_grid / d_out / d_tmp: W*H*D elements of the dtype
+ * (complex: interleaved parts), none aliased.  64-bit integers go through a double exactly as in SciPy. */
+enum {
+    PB3D_I8 = 1, PB3D_U8 = 2, PB3D_I16 = 3, PB3D_U16 = 4, PB3D_I32 = 5, PB3D_U32 = 6, PB3D_I64 = 7, PB3D_U64 = 8,
+    PB3D_F32 = 9, PB3D_F64 = 10, PB3D_C64 = 11, PB3D_C128 = 12
+};
+size_t pb3d_dtype_bytes(int dtype);      /* bytes per element, 0 for an unknown code */
+int pb3d_process_grid_typed_dev(pb3d_ctx* ctx, const void* d_grid, int dtype, int64_t W, int64_t H, int64_t D, const uint8_t* d_mask_wh,
+                                int angle_interval, void* d_out, void* d_tmp);
+
 /* ---- _occupancy, reference utils/voxel_carving_utils.py:32-33: any(grid > 0, axis=-1) ---- */
 int pb3d_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t nvox, uint8_t* d_occ);
 int pb3d_occupancy(pb3d_ctx* ctx, const uint8_t* grid_rgb, int64_t nvox, uint8_t* occ);

@@ -510,3 +510,90 @@ def project_part_visible(pts3d, cam, zbuf, H, W, eps=1e-3):
                            C.c_double(float(cam["cx"])), C.c_double(float(cam["cy"])), prec, zb.ctypes.data_as(C.POINTER(C.c_float)),
                            int(H), int(W), C.c_double(float(eps)), eps_f32, _p(mask))
     return mask.astype(bool)
+
+
+# =====================================================================================================
+# Grids of any dtype SciPy's interpolation takes (bool, int8..int64, uint8..uint64, float32/64, complex64/128) through the rotate + carve
+# loop -- reference utils/voxel_carving_utils.py:104-126 does not look at the dtype: scipy.ndimage.affine_transform(order=1,
+# mode="constant", cval=0) returns the input's dtype, carve_voxel_grid_with_masks (np.where) keeps it.  A NumPy restatement (float64 array
+# operations are IEEE and unfused, in the order of the scalar form above), pinned against SciPy itself in tests/test_oracle_golden.py.
+#   value:  acc = (((v00*wx0)*wz0 + (v01*wx0)*wz1) + (v10*wx1)*wz0) + (v11*wx1)*wz1, taps with an exactly-zero weight skipped
+#   store (ni_interpolation.c, CASE_INTERP_OUT*): floats (T)acc; unsigned: acc > 0 ? acc + 0.5 : 0, clipped to [0, MAX], truncated;
+#           signed: acc > 0 ? acc + 0.5 : acc - 0.5, clipped to [MIN, MAX], truncated; bool: (unsigned char)acc (truncation) != 0 ...
+#           complex: real and imaginary parts separately (scipy/ndimage/_interpolation.py splits them)
+# =====================================================================================================
+TYPED_DTYPES = ("bool", "int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64", "complex64", "complex128")
+
+
+def _store_typed(acc, dtype):
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        return acc.astype(dt)
+    if dt.kind == "b":
+        return acc.astype(np.uint8).astype(bool)          # C cast double -> unsigned char: truncation (acc is within [0, 1])
+    info = np.iinfo(dt)
+    if dt.kind == "u":
+        t = np.where(acc > 0, acc + 0.5, 0.0)
+        t = np.where(t > float(info.max), float(info.max), t)
+        t = np.where(t < 0, 0.0, t)
+    else:
+        t = np.where(acc > 0, acc + 0.5, acc - 0.5)
+        t = np.where(t > float(info.max), float(info.max), t)
+        t = np.where(t < float(info.min), float(info.min), t)
+    with np.errstate(invalid="ignore"):
+        if dt.itemsize == 8:
+            # the C cast of a double that equals 2^63 (int64) / 2^64 (uint64) after the clip is out of range; on x86-64 it yields INT64_MIN /
+            # (for the unsigned conversion sequence) 2^63 ... SciPy's result, whatever the platform gives -- test data stay below 2^62
+            return np.trunc(t).astype(dt)
+        return np.trunc(t).astype(np.int64).astype(dt)
+
+
+def affine_transform_typed(grid, M, off):
+    g = np.ascontiguousarray(grid)
+    if g.dtype.name not in TYPED_DTYPES:
+        raise RuntimeError("data type not supported")
+    if g.dtype.kind == "c":
+        out = np.empty_like(g)
+        out.real = affine_transform_typed(np.ascontiguousarray(g.real), M, off)
+        out.imag = affine_transform_typed(np.ascontiguousarray(g.imag), M, off)
+        return out
+    W, H, D = g.shape
+    M = np.asarray(M, np.float64).reshape(3, 3); off = np.asarray(off, np.float64)
+    x = np.arange(W, dtype=np.float64)[:, None]; z = np.arange(D, dtype=np.float64)[None, :]
+    def coord(ma, mb, mc, o):
+        c = 0.0 + x * ma
+        c = c + 0.0 * mb
+        c = c + z * mc
+        return c + o
+    cc0 = coord(M[0, 0], M[0, 1], M[0, 2], off[0]); cc2 = coord(M[2, 0], M[2, 1], M[2, 2], off[2])
+    inside = ~((cc0 < 0.0) | (cc0 > W - 1) | (cc2 < 0.0) | (cc2 > D - 1))
+    f0 = np.floor(np.where(inside, cc0, 0.0)); f2 = np.floor(np.where(inside, cc2, 0.0))
+    s0 = f0.astype(np.int64); s2 = f2.astype(np.int64)
+    wx0 = 1.0 - (np.where(inside, cc0, 0.0) - f0); wx1 = 1.0 - wx0
+    wz0 = 1.0 - (np.where(inside, cc2, 0.0) - f2); wz1 = 1.0 - wz0
+    s0b = np.minimum(s0 + 1, W - 1); s2b = np.minimum(s2 + 1, D - 1)      # (a tap beyond the last index only ever has weight 0)
+    gd = g.astype(np.float64)
+    acc = np.zeros((W, H, D), np.float64)
+    def tap(a, b, wa, wb):
+        v = gd[a[:, None, :], np.arange(H)[None, :, None], b[:, None, :]]
+        prod = (v * wa[:, None, :]) * wb[:, None, :]
+        live = ((wa != 0.0) & (wb != 0.0))[:, None, :]
+        return np.where(live, prod, 0.0), live
+    for (a, b, wa, wb) in ((s0, s2, wx0, wz0), (s0, s2b, wx0, wz1), (s0b, s2, wx1, wz0), (s0b, s2b, wx1, wz1)):
+        pr, live = tap(a, b, wa, wb)
+        acc = np.where(live, acc + pr, acc)
+    acc = np.where(inside[:, None, :], acc, 0.0)
+    return _store_typed(acc, g.dtype)
+
+
+def process_voxel_grid_typed(voxel_grid, combined_mask, angle_interval=90):
+    """process_voxel_grid (reference :104-126) for any dtype SciPy's interpolation takes."""
+    g = np.ascontiguousarray(voxel_grid)
+    W, H, D = g.shape
+    m = mask_to_wh(combined_mask, W, H)
+    keep = (np.asarray(m) != 0)[:, :, None]
+    for angle in range(0, 91, int(angle_interval)):
+        Minv = rotation_matrix_inv(angle)
+        g = affine_transform_typed(g, Minv, affine_offset(Minv, (W, H, D)))
+        g = np.where(keep, g, 0)          # (as upstream: a bool grid comes back as int64 -- NumPy's promotion of the Python 0)
+    return g

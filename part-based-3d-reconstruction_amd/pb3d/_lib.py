@@ -48,6 +48,8 @@ _SIGNATURES = {
     "pb3d_rotate_carve": [vp, u8p, i64, i64, i64, dblp, dblp, u8p, u8p],
     "pb3d_process_grid_dev": [vp, vp, i64, i64, i64, vp, C.c_int, vp, vp],
     "pb3d_process_grid": [vp, u8p, i64, i64, i64, u8p, C.c_int, u8p],
+    "pb3d_dtype_bytes": [C.c_int],
+    "pb3d_process_grid_typed_dev": [vp, vp, C.c_int, i64, i64, i64, vp, C.c_int, vp, vp],
     "pb3d_occupancy_dev": [vp, vp, i64, vp],
     "pb3d_occupancy": [vp, u8p, i64, u8p],
     "pb3d_color_apply_dev": [vp, vp, i64, i64, i64, vp, vp],
@@ -113,7 +115,7 @@ _SIGNATURES = {
     "pb3d_project_resolve_keys_dev": [vp, vp, C.c_int, C.c_int, vp],
     "pb3d_allreduce_max_u64_dev": [vp, vp, C.c_size_t],
 }
-_RESTYPES = {"pb3d_last_error": C.c_char_p, "pb3d_destroy": None, "pb3d_event_destroy": None}
+_RESTYPES = {"pb3d_dtype_bytes": C.c_size_t, "pb3d_last_error": C.c_char_p, "pb3d_destroy": None, "pb3d_event_destroy": None}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

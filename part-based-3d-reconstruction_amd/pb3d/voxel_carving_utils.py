@@ -66,6 +66,8 @@ def carve_voxel_grid_with_masks(voxel_grid, combined_mask):
             return out
         # Any other numeric dtype / channel count: np.where(mask, grid, 0) keeps the grid's dtype and either copies an element
         # bit for bit or writes a zero, so the op is "zero the bytes of the dropped (x,y) columns" whatever the elements are.
+        if g.dtype == np.bool_:
+            g = g.astype(np.result_type(g.dtype, 0))          # np.where(mask, bool_grid, 0) is an int64 grid (NumPy's promotion of the Python 0)
         if g.dtype.kind not in "uifc" or np.result_type(g.dtype, 0) != g.dtype:
             raise TypeError(f"voxel_grid dtype {g.dtype} is not supported (np.where would change it); use a numeric dtype")
         col_bytes = int(np.prod(g.shape[2:], dtype=np.int64)) * g.dtype.itemsize
@@ -82,10 +84,14 @@ def carve_voxel_grid_with_masks(voxel_grid, combined_mask):
     raise ValueError("Unsupported mask shape")
 
 
+_TYPED_CODES = {"int8": 1, "uint8": 2, "int16": 3, "uint16": 4, "int32": 5, "uint32": 6, "int64": 7, "uint64": 8, "float32": 9,
+                "float64": 10, "complex64": 11, "complex128": 12}       # include/pb3d.h PB3D_I8 ..
+
+
 def process_voxel_grid(voxel_grid, combined_mask, angle_interval=90):
     """for angle in range(0, 91, angle_interval): rotate about Y (trilinear, SciPy semantics) and
     carve; cumulative, never rotated back.  reference :104-126.  The loop runs on the device."""
-    g = _lib.as_u8(voxel_grid, "voxel_grid")
+    g = np.ascontiguousarray(np.asarray(voxel_grid))
     if g.ndim != 3:
         raise ValueError(f"process_voxel_grid rotates occupancy grids (W,H,D); got shape {g.shape}")
     W, H, D = g.shape
@@ -95,10 +101,30 @@ def process_voxel_grid(voxel_grid, combined_mask, angle_interval=90):
         raise ValueError("range() arg 3 must not be zero")
     if angle_interval < 0:
         return g.copy()  # range(0, 91, negative) is empty: upstream returns the input grid
+    if g.dtype == np.bool_:
+        g = g.astype(np.int64)      # upstream's first np.where(mask, grid, 0) turns a bool grid into int64 (the 0-degree step before it is the identity)
+    typed = _TYPED_CODES.get(g.dtype.name) if g.dtype != np.uint8 else None
+    if g.dtype != np.uint8 and typed is None:
+        # what SciPy's interpolation says to a dtype it does not take (float16, object, strings ...)
+        raise RuntimeError("data type not supported")
     mask = _mask_to_wh(combined_mask, W, H)
     if mask.ndim != 2:
         carve_voxel_grid_with_masks(g, combined_mask)  # raises what upstream raises
     m = _lib.truth_u8(mask)
+    if typed is not None:
+        # any other dtype SciPy's interpolation takes (the reference's loop never looks at it): csrc/rotate_typed.hip
+        from . import device as dev
+        if g.size == 0:
+            return g.copy()
+        d_g = dev.from_numpy(g.view(np.uint8).reshape(-1)); d_m = dev.from_numpy(m)
+        d_o = dev.DeviceBuffer(g.nbytes); d_t = dev.DeviceBuffer(g.nbytes)
+        try:
+            _lib.check(_lib.load().pb3d_process_grid_typed_dev(_lib.ctx(), C.c_void_p(d_g.ptr), typed, W, H, D, C.c_void_p(d_m.ptr),
+                                                               int(min(angle_interval, 91)), C.c_void_p(d_o.ptr), C.c_void_p(d_t.ptr)))
+            return d_o.download((g.nbytes,)).view(g.dtype).reshape(g.shape)
+        finally:
+            for b in (d_g, d_m, d_o, d_t):
+                b.free()
     out = _hostmem.empty_like(g)
     _lib.check(_lib.load().pb3d_process_grid(_lib.ctx(), _lib.p_u8(g), W, H, D, _lib.p_u8(m), int(min(angle_interval, 91)),
                                              _lib.p_u8(out)))

@@ -179,8 +179,10 @@ def test_carve_vs_oracle_shapes(pb3d_gpu, oracle):
         got = pb3d_gpu.carve_voxel_grid_with_masks(grid, m)
         want = np.where(m.T[:, :, None] if not tail else m.T[:, :, None, None], grid, 0)
         assert got.dtype == want.dtype == np.dtype(dt) and np.array_equal(got, want), dt
+    gb = pb3d_gpu.carve_voxel_grid_with_masks(np.ones((3, 3, 3), bool), np.eye(3, dtype=bool))      # np.where(mask, bool_grid, 0): int64
+    assert gb.dtype == np.int64 and np.array_equal(gb, np.where(np.eye(3, dtype=bool).T[:, :, None], np.ones((3, 3, 3), bool), 0))
     with pytest.raises(TypeError):
-        pb3d_gpu.carve_voxel_grid_with_masks(np.ones((3, 3, 3), bool), np.ones((3, 3), bool))
+        pb3d_gpu.carve_voxel_grid_with_masks(np.array([[["a"]]]), np.ones((1, 1), bool))
     # empty grids
     for shp in [(0, 4, 4), (4, 0, 4), (4, 4, 0)]:
         e = np.zeros(shp, np.uint8)
@@ -1495,6 +1497,43 @@ def test_rot90_mask_blocks_random_shapes(pb3d_gpu, oracle):
             finally:
                 pb3d_gpu._lib.set_tuning("misc5", 0)
             assert np.array_equal(got, want), (W, H, D, misc5, int((got != want).any(-1).sum()))
+
+
+def test_process_voxel_grid_other_dtypes(pb3d_gpu, oracle, golden):
+    """process_voxel_grid on grids that are not uint8 (csrc/rotate_typed.hip): the reference's own outputs for every dtype SciPy's
+    interpolation takes (fixture f12), then larger seeded grids against the restatement; float16 is refused as SciPy refuses it; a bool
+    grid comes back as int64 (upstream's np.where(mask, grid, 0)), from carve_voxel_grid_with_masks too."""
+    g = golden("f12_process_typed")
+    for k in g["cases"]:
+        k = str(k)
+        got = pb3d_gpu.process_voxel_grid(g[k + "_in"], g[k + "_mask"], int(k.split("_")[-1]))
+        want = g[k + "_out"]
+        assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), k
+    rng = np.random.default_rng(91)
+    for dt in ("bool", "int8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64", "complex64", "complex128"):
+        for (W, H, D), ang in (((70, 9, 65), 5), ((64, 5, 64), 45), ((33, 4, 300), 90), ((1, 1, 1), 30)):
+            if dt == "bool":
+                a = rng.random((W, H, D)) < 0.5
+            elif dt.startswith("complex"):
+                a = ((rng.random((W, H, D)) * 400 - 200) + 1j * (rng.random((W, H, D)) * 10 - 5)).astype(dt)
+            elif dt.startswith("float"):
+                a = (rng.random((W, H, D)) * 400 - 200).astype(dt)
+            elif dt.startswith("u"):
+                a = (rng.random((W, H, D)) * min(float(np.iinfo(dt).max), 2.0 ** 45)).astype(dt)
+            else:
+                a = ((rng.random((W, H, D)) - 0.5) * min(float(np.iinfo(dt).max), 2.0 ** 45) * 2).astype(dt)
+            m = rng.random((H, W)) < 0.8
+            want = oracle.process_voxel_grid_typed(a, m, ang)
+            got = pb3d_gpu.process_voxel_grid(a, m, ang)
+            assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dt, W, H, D, ang, int((got != want).sum()))
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        pb3d_gpu.process_voxel_grid(np.zeros((4, 3, 4), np.float16), np.ones((3, 4), bool), 45)
+    b = rng.random((6, 5, 7)) < 0.5
+    mb = rng.random((5, 6)) < 0.6
+    got = pb3d_gpu.carve_voxel_grid_with_masks(b, mb)
+    want = np.where(mb.T[:, :, None], b, 0)
+    assert got.dtype == want.dtype == np.int64 and np.array_equal(got, want)
+    assert pb3d_gpu.process_voxel_grid(b, mb, -3).dtype == np.bool_        # the empty angle loop returns the grid as it came
 
 
 def test_recolour_entries_agree(pb3d_gpu, oracle):

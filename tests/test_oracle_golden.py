@@ -319,3 +319,36 @@ def test_five_monuments_deformation_loop_m5(oracle, mon):
         saved[part] = {"deform": c["deform"], "iou": iou}
     full = oracle.build_deformed_grid(grid, PC, saved, meta["image_shape"])
     assert sha(full) == meta["deformed_grid_sha256"]
+
+
+def test_process_other_dtypes_f12(oracle, golden):
+    """process_voxel_grid on grids that are not uint8 (fixture: the reference's own function on every dtype SciPy's interpolation takes --
+    tools/gen_golden_typed.py): the restatement returns the same bytes and the same dtype (a bool grid comes back as int64: upstream's
+    np.where(mask, grid, 0)); and, where SciPy is importable, one interpolation step agrees with scipy.ndimage.affine_transform itself."""
+    g = golden("f12_process_typed")
+    assert len(g["cases"]) == 48
+    for k in g["cases"]:
+        k = str(k)
+        got = oracle.process_voxel_grid_typed(g[k + "_in"], g[k + "_mask"], int(k.split("_")[-1]))
+        want = g[k + "_out"]
+        assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), k
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(3)
+    for dt in oracle.TYPED_DTYPES:
+        for (W, H, D), ang in (((9, 3, 11), 5), ((16, 2, 16), 45), ((7, 4, 5), 60), ((12, 2, 12), 90)):
+            if dt == "bool":
+                a = rng.random((W, H, D)) < 0.5
+            elif dt.startswith("complex"):
+                a = ((rng.random((W, H, D)) * 400 - 200) + 1j * (rng.random((W, H, D)) * 10 - 5)).astype(dt)
+            elif dt.startswith("float"):
+                a = (rng.random((W, H, D)) * 400 - 200).astype(dt)
+            elif dt.startswith("u"):
+                a = (rng.random((W, H, D)) * min(float(np.iinfo(dt).max), 2.0 ** 40)).astype(dt)
+            else:
+                a = ((rng.random((W, H, D)) - 0.5) * min(float(np.iinfo(dt).max), 2.0 ** 40) * 2).astype(dt)
+            M = oracle.rotation_matrix_inv(ang); c = np.array([W, H, D]) / 2
+            want = ndi.affine_transform(a, M, offset=c - M @ c, order=1, mode="constant", cval=0)
+            got = oracle.affine_transform_typed(a, M, oracle.affine_offset(M, (W, H, D)))
+            assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dt, W, H, D, ang)
+    with pytest.raises(RuntimeError, match="data type not supported"):
+        oracle.affine_transform_typed(np.zeros((3, 3, 3), np.float16), np.eye(3), np.zeros(3))
