@@ -45,6 +45,18 @@ def main():
             pb3d._lib.set_tuning("rotate_tile", tile)
             ok("process", pb3d.process_voxel_grid(g, m, ai), want, info + (tile,))
         pb3d._lib.set_tuning("rotate_tile", 0)
+        if n % 4 == 1 and W * H * D <= 300000:       # the same loop on a grid of another dtype (csrc/rotate_typed.hip), bytes and dtype compared
+            dt = str(rng.choice(["bool", "int8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64", "complex64", "complex128"]))
+            if dt == "bool": gt = rng.random((W, H, D)) < dens
+            elif dt.startswith("complex"): gt = ((rng.random((W, H, D)) * 400 - 200) + 1j * (rng.random((W, H, D)) * 10 - 5)).astype(dt)
+            elif dt.startswith("float"): gt = (rng.random((W, H, D)) * 400 - 200).astype(dt)
+            elif dt.startswith("u"): gt = (rng.random((W, H, D)) * min(float(np.iinfo(dt).max), 2.0 ** 45)).astype(dt)
+            else: gt = ((rng.random((W, H, D)) - 0.5) * min(float(np.iinfo(dt).max), 2.0 ** 45) * 2).astype(dt)
+            gt[rng.random((W, H, D)) > dens] = 0
+            wt = oracle.process_voxel_grid_typed(gt, m, ai); ot = pb3d.process_voxel_grid(gt, m, ai)
+            ok("process_typed", ot.view(np.uint8), wt.view(np.uint8), info + (dt,))
+            if ot.dtype != wt.dtype:
+                print("MISMATCH process_typed dtype", info, dt, ot.dtype, wt.dtype, flush=True); sys.exit(1)
         col = pal[rng.integers(0, len(pal), (W, H, D))] * (rng.random((W, H, D, 1)) < dens).astype(np.uint8)
         ok("carve_rgb", pb3d.carve_voxel_grid_with_masks(col, m), oracle.carve_voxel_grid_with_masks(col, m), info)
         ok("carve_occ", pb3d.carve_voxel_grid_with_masks(g, m), oracle.carve_voxel_grid_with_masks(g, m), info)
