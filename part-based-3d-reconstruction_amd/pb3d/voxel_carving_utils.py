@@ -131,6 +131,11 @@ def process_voxel_grid(voxel_grid, combined_mask, angle_interval=90):
     return out
 
 
+def _rotate_and_carve(grid, mask, angle_interval):
+    """reference :47-60 -- the loop of process_voxel_grid without the progress bar (upstream keeps it next to the public function; unused there)."""
+    return process_voxel_grid(grid, mask, angle_interval)
+
+
 def apply_colored_mask_to_voxel_grid(carved_voxel_grid, colored_mask):
     """out[x,y,z,:] = colored_mask[y,x,:] where carved == 1 else 0; reference :128-136."""
     cv = _lib.as_u8(carved_voxel_grid, "carved_voxel_grid")
