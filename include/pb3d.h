@@ -274,10 +274,23 @@ int pb3d_label_color_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, i
 int pb3d_label_color_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3],
                                int32_t* d_labels, int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count,
                                int64_t* coord_sum, int* stats_valid);
-/* members_only = 1: the entries of d_labels at voxels that do NOT carry the colour are left UNWRITTEN (the zeros are more than half of the
+/* members_only = 1: the entries of d_labels at voxels that do NOT carry the colour are left UNSPECIFIED (the zeros are more than half of the
  * labelling's traffic).  Such a volume may only be consumed, before the next pb3d_label_* call on the context, by the entries that
- * consult the labelling's membership bits: pb3d_guided_carve[_label]_dev and pb3d_recolor_last_labelled_dev (and by reading the labels
- * of voxels known to carry the colour).  members_only = 0: a full label volume (0 elsewhere), as pb3d_label_color_dev writes. */
+ * consult the labelling's membership bits: pb3d_guided_carve[_label | _color]_dev and pb3d_recolor_last_labelled_dev (and by reading the
+ * labels of voxels known to carry the colour).  members_only = 0: a full label volume (0 elsewhere), as pb3d_label_color_dev writes.
+ * The bits stay valid until the next pb3d_label_* call on the context (calls that only grow OTHER scratch buffers, e.g.
+ * pb3d_component_stats_dev, do not invalidate them). */
+/* The components of SEVERAL colours in ONE labelling sequence (reference utils/voxel_carving_utils.py:338 calls :175 once per part colour
+ * on a grid whose membership of the OTHER colours left_right_guided_carve never changes: it only clears or restores voxels of its own
+ * colour, :199-201): the colour grid is read once, one forest serves every colour (a run = a maximal run of one colour).  colors =
+ * ncolors x 3 bytes, pairwise different, 1 <= ncolors <= PB3D_CCL_MAX_COLORS.  ncomp[k], stats_valid[k] per colour; the statistics arrays
+ * are [ncolors][cap][...]; labels are numbered PER COLOUR (as one scipy.ndimage.label call per colour numbers them), so the label of a
+ * voxel means something only together with its colour: d_labels is for the consumers that take a colour index
+ * (pb3d_guided_carve_color_dev) or, with ncolors == 1, for anyone. */
+#define PB3D_CCL_MAX_COLORS 8
+int pb3d_label_colors_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const uint8_t* colors, int ncolors,
+                                int32_t* d_labels, int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count,
+                                int64_t* coord_sum, int* stats_valid);
 int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0, int64_t A1, int64_t A2, int64_t ncomp,
                              int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum);
 int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
@@ -294,6 +307,11 @@ int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int3
 int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                           const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                           int64_t* carved_counts, int* took);
+/* ... for colour `color_index` of the last pb3d_label_colors_stats_dev / pb3d_label_values_stats_dev call on the context (d_labels is the
+ * volume that call wrote; channels = 3: colour grid, 1: label volume).  PB3D_EINVAL when the labelling's membership bits are gone. */
+int pb3d_guided_carve_color_dev(pb3d_ctx* ctx, uint8_t* d_grid, const int32_t* d_labels, int color_index, int channels, int64_t W, int64_t H,
+                                int64_t D, int64_t ncomp, const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off,
+                                int64_t mask_bytes, int angle_interval, int64_t* carved_counts, int* took);
 /* The rest of the notebook-1 chain on the 1-byte LABEL form of a palette grid (row N3; label 0 = empty, the others index a palette):
  * the same kernels with one byte per voxel -- components of the voxels that carry `value`, the fused component loop, extrusion
  * (fill_label < 0: clear), recolouring and the output orientation.  Expanding a result with the palette gives the bytes of the RGB
@@ -301,6 +319,9 @@ int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_l
 int pb3d_label_value_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, uint8_t value, int32_t* d_labels,
                                int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count, int64_t* coord_sum,
                                int* stats_valid);
+int pb3d_label_values_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, const uint8_t* values, int nvalues,
+                                int32_t* d_labels, int64_t* ncomp, int64_t cap, int members_only, int64_t* bbox_lo_hi, int64_t* count,
+                                int64_t* coord_sum, int* stats_valid);
 int pb3d_guided_carve_label_dev(pb3d_ctx* ctx, uint8_t* d_grid_lab, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                                 const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                                 int64_t* carved_counts, int* took);

@@ -38,6 +38,8 @@ _i64 = C.c_int64
 
 
 def build(force=False):
+    if os.environ.get("PB3D_ORACLE_LIB"):       # a sanitizer build of the same file (make -C oracle SAN=1; README "Sanitizers")
+        return os.environ["PB3D_ORACLE_LIB"]
     so = os.path.join(_HERE, "libpb3d_oracle.so")
     src = os.path.join(_HERE, "pb3d_oracle.c")
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):

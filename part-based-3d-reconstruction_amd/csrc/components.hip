@@ -471,7 +471,8 @@ static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, co
     PB3D_HIP(hipMemcpyAsync(f, comp_flag, (size_t)ncomp, hipMemcpyHostToDevice, ctx->stream));
     PB3D_HIP(hipStreamSynchronize(ctx->stream));   // comp_flag is a caller-owned host buffer
     const pb3d_ctx::CclLast& cl = ctx->ccl_last;
-    const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows * cl.A2 == nvox && cl.gen == ctx->scratch_gen && cl.rows * cl.P < (1ll << 32);
+    const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows * cl.A2 == nvox && cl.gen == ctx->scratch_slot_gen[42] &&
+                         cl.rows * cl.P < (1ll << 32) && cl.K == 1;
     PB3D_REQUIRE(!last_labelled || bits_ok, "pb3d_recolor_last_labelled: d_labels is not the volume the last pb3d_label_* call on this context wrote");
     if (last_labelled) {
         const i64 nwords = cl.rows * cl.P;

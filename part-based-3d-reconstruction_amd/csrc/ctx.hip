@@ -119,6 +119,15 @@ int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "s32_gpw")) {
         PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: s32_gpw is a count of plane groups");
         ctx->tune_s32_gpw = value;
+    } else if (!strcmp(name, "ccl_blocks")) {
+        PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: ccl_blocks is a count of workgroups per CU");
+        ctx->tune_ccl_blocks = value;
+    } else if (!strcmp(name, "ccl_tilecols")) {
+        PB3D_REQUIRE(value >= 0 && value <= 64, "pb3d_set_tuning: ccl_tilecols is at most 64");
+        ctx->tune_ccl_tilecols = value;
+    } else if (!strcmp(name, "ccl_merge")) {
+        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: ccl_merge is 0 (tile kernels) or 1 (pairwise kernel)");
+        ctx->tune_ccl_merge = value;
     } else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '5' && !name[5]) {
         ctx->tune_misc[name[4] - '0'] = value;
     } else {
@@ -354,6 +363,7 @@ int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
         PB3D_HIP(pool_malloc(ctx, &ctx->scratch[slot], padded));
         ctx->scratch_bytes[slot] = padded;
         ++ctx->scratch_gen;
+        ++ctx->scratch_slot_gen[slot];
     }
     *out = ctx->scratch[slot];
     return PB3D_OK;

@@ -199,7 +199,7 @@ static bool boxes_overlap(const i64* a, const i64* b) {
 
 static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                              const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
-                             int64_t* carved_counts, int* took, int C) {
+                             int64_t* carved_counts, int* took, int C, int color_index) {
     PB3D_REQUIRE(ctx && took && W >= 0 && H >= 0 && D >= 0 && ncomp >= 0, "pb3d_guided_carve: bad argument");
     *took = 0;
     PB3D_REQUIRE(angle_interval > 0, "pb3d_guided_carve: angle_interval must be a positive integer (got %d)", angle_interval);
@@ -222,8 +222,14 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
     }
     // labels of the last labelling on this context: its membership bits are still on the device
     const pb3d_ctx::CclLast& cl = ctx->ccl_last;
-    const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows == W * H && cl.A2 == D && cl.gen == ctx->scratch_gen;
-    const u64* mb64 = bits_ok ? (const u64*)cl.bits : nullptr;
+    const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows == W * H && cl.A2 == D && cl.gen == ctx->scratch_slot_gen[42] &&
+                         color_index >= 0 && color_index < cl.K;
+    // Without the bits the kernel reads labels[] at every voxel of a crop: that is only right for a FULL label volume of ONE colour.  A volume
+    // this context wrote for the members only (or for several colours, numbered per colour) must not be read that way.
+    PB3D_REQUIRE(bits_ok || (color_index == 0 && !(cl.labels == (const void*)d_labels && (cl.members_only || cl.K > 1))),
+                 "pb3d_guided_carve: the membership bits of this label volume are gone (it was labelled for the members only or for several colours): "
+                 "label again before carving");
+    const u64* mb64 = bits_ok ? (const u64*)cl.bits + (i64)color_index * cl.rows * cl.P : nullptr;
     const int mbP = bits_ok ? (int)cl.P : 0;
     if (!ctx->guided_lds_set) {
         PB3D_HIP(hipFuncSetAttribute((const void*)k_crop_chain, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
@@ -354,14 +360,24 @@ extern "C" {
 int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                           const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                           int64_t* carved_counts, int* took) {
-    return guided_carve_impl(ctx, d_grid_rgb, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, 3);
+    return guided_carve_impl(ctx, d_grid_rgb, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, 3, 0);
+}
+
+// ... for colour `color_index` of a labelling of several colours (pb3d_label_colors_stats_dev / pb3d_label_values_stats_dev)
+int pb3d_guided_carve_color_dev(pb3d_ctx* ctx, uint8_t* d_grid, const int32_t* d_labels, int color_index, int channels, int64_t W, int64_t H,
+                                int64_t D, int64_t ncomp, const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off,
+                                int64_t mask_bytes, int angle_interval, int64_t* carved_counts, int* took) {
+    PB3D_REQUIRE(channels == 1 || channels == 3, "pb3d_guided_carve_color: channels is 1 (labels) or 3 (colours)");
+    PB3D_REQUIRE(ctx && color_index >= 0 && color_index < PB3D_CCL_MAX_COLORS, "pb3d_guided_carve_color: bad colour index");
+    return guided_carve_impl(ctx, d_grid, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, channels,
+                             color_index);
 }
 
 // the same on a 1-byte LABEL volume (row N3): occupancy = label != 0, cleared voxels get label 0
 int pb3d_guided_carve_label_dev(pb3d_ctx* ctx, uint8_t* d_grid_lab, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                                 const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                                 int64_t* carved_counts, int* took) {
-    return guided_carve_impl(ctx, d_grid_lab, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, 1);
+    return guided_carve_impl(ctx, d_grid_lab, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, 1, 0);
 }
 
 }  // extern "C"

@@ -40,6 +40,9 @@ struct pb3d_ctx {
     bool rot90w_lds_set;
     bool rot90wf_lds_set;       // ... and for its form on the rows' (y, z) streams (odd row lengths)
     int tune_s32_gpw;           // PB3D_S32_GPW: plane groups per workgroup of the sliced step kernel (0 = choose)
+    int tune_ccl_blocks;        // knob "ccl_blocks": workgroups per CU of the labelling's last pass (0 = default)
+    int tune_ccl_tilecols;      // knob "ccl_tilecols": windows per level of a plane-to-plane merge tile (0 = 32)
+    int tune_ccl_merge;         // knob "ccl_merge": 0 = tile kernels where the rows fit, 1 = always the pairwise kernel (development A/B)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).
     void* scratch[PB3D_NSCRATCH];
@@ -82,7 +85,9 @@ struct pb3d_ctx {
     struct S32Cache { bool valid; u64 gen; i64 W, D; int ns; double p[32 * 8]; } s32_cache;
     hipEvent_t s32_ev;          // recorded behind the slice kernel's "not 0/1" flag copy
     // membership bits of the last labelled volume (csrc/ccl.hip, scratch slot 42): word row * P + t, bit = voxel is a member
-    struct CclLast { bool valid; const void* labels; const void* bits; i64 rows, A2, P; u64 gen; bool members_only; } ccl_last;
+    // of colour k (K colours labelled together, csrc/ccl.hip: their numbering is per colour, so a label needs its colour's bits to mean anything
+    // once K > 1).  gen = scratch_slot_gen[42] when the bits were written: only a reallocation of THAT slot invalidates them.
+    struct CclLast { bool valid; const void* labels; const void* bits; i64 rows, A2, P; u64 gen; bool members_only; int K, C; u32 colors[PB3D_CCL_MAX_COLORS]; } ccl_last;
     void* flag_ring;            // the ring of "value > 1 seen" flag words of the generic-angle steps (scratch slot 15) and its position
     u64 flag_gen;
     hipStream_t aux_stream;     // table builds that overlap the main stream's kernels
@@ -98,6 +103,7 @@ struct pb3d_ctx {
     size_t pool_cached, pool_cap;       // bytes held in pool_free; its limit (PB3D_DEVICE_POOL_MB, default a quarter of the HBM, 0 = off)
     u64 pool_stamp;
     u64 scratch_gen;            // bumped whenever ANY scratch slot is reallocated (cached tables in other slots may have moved)
+    u64 scratch_slot_gen[PB3D_NSCRATCH];    // ... and per slot
     // RCCL (loaded lazily with dlopen; see comm.hip)
     void* rccl_lib;
     void* rccl_comm;

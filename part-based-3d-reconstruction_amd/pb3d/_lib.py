@@ -81,6 +81,9 @@ _SIGNATURES = {
     "pb3d_scatter_colors_dev": [vp, vp, vp, i64, i64, i64, i64, vp],
     "pb3d_label_color_dev": [vp, vp, i64, i64, i64, u8p, vp, i64p],
     "pb3d_label_color_stats_dev": [vp, vp, i64, i64, i64, u8p, vp, i64p, i64, C.c_int, i64p, i64p, i64p, intp],
+    "pb3d_label_colors_stats_dev": [vp, vp, i64, i64, i64, u8p, C.c_int, vp, i64p, i64, C.c_int, i64p, i64p, i64p, intp],
+    "pb3d_label_values_stats_dev": [vp, vp, i64, i64, i64, u8p, C.c_int, vp, i64p, i64, C.c_int, i64p, i64p, i64p, intp],
+    "pb3d_guided_carve_color_dev": [vp, vp, vp, C.c_int, C.c_int, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, i64p, intp],
     "pb3d_component_stats_dev": [vp, vp, i64, i64, i64, i64, i64p, i64p, i64p],
     "pb3d_crop_occupancy_dev": [vp, vp, i64, i64, i64, i64p, i64p, vp],
     "pb3d_component_paste_dev": [vp, vp, vp, C.c_int32, vp, i64, i64, i64, i64p, i64p, vp],

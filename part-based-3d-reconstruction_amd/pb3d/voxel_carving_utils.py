@@ -375,6 +375,27 @@ def _label_stats(d_grid, shape3, color_u8, d_labels, cap=1024, members_only=Fals
     return n.value, bbox[:n.value], cnt[:n.value], sums[:n.value]
 
 
+def _label_stats_multi(d_grid, shape3, colors, d_labels, cap=1024, members_only=True):
+    """The components of SEVERAL colours (or label values) in one labelling sequence and one host round trip
+    (pb3d_label_colors_stats_dev: the grid is read once; labels are numbered per colour).  `colors`: a list of 3-byte colours, or of ints
+    for a 1-byte label volume.  Returns a list of (n, bbox, count, sums) per colour; an entry is None where the colour has more than
+    `cap` components (the caller labels that colour on its own)."""
+    A0, A1, A2 = shape3
+    K = len(colors)
+    lib = _lib.load()
+    n = (C.c_int64 * K)(); ok = (C.c_int * K)()
+    bbox = np.zeros((K, cap, 6), np.int64); cnt = np.zeros((K, cap), np.int64); sums = np.zeros((K, cap, 3), np.int64)
+    if isinstance(colors[0], (int, np.integer)):
+        cols = np.ascontiguousarray(np.asarray(colors, np.uint8))
+        fn = lib.pb3d_label_values_stats_dev
+    else:
+        cols = np.ascontiguousarray(np.asarray(colors, np.uint8).reshape(K, 3))
+        fn = lib.pb3d_label_colors_stats_dev
+    _lib.check(fn(_lib.ctx(), C.c_void_p(d_grid.ptr), A0, A1, A2, _lib.p_u8(cols), K, C.c_void_p(d_labels.ptr), n, cap, 1 if members_only else 0,
+                  bbox.ctypes.data_as(_lib.i64p), cnt.ctypes.data_as(_lib.i64p), sums.ctypes.data_as(_lib.i64p), ok))
+    return [((n[k], bbox[k, :n[k]], cnt[k, :n[k]], sums[k, :n[k]]) if ok[k] else None) for k in range(K)]
+
+
 def _check_angle_step(angle):
     if isinstance(angle, (bool, np.bool_)) or not isinstance(angle, (int, np.integer)):
         raise TypeError(f"'{type(angle).__name__}' object cannot be interpreted as an integer")

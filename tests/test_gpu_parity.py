@@ -465,10 +465,69 @@ def test_connected_components_row_frame_shapes(pb3d_gpu, oracle):
                 n3, b3, c3, s3 = _label_stats(d_g, shp, col, d_l3, cap=4096, members_only=True)
                 got3 = d_l3.download(shp, np.int32)
                 # (more components than the capacity: the call falls back to a FULL labelling -- zeros outside)
-                assert n3 == n and np.array_equal(got3[mask], want[mask]) and np.all(got3[~mask] == (-7 if n <= 4096 else 0)), (shp, dens)
+                # (the entries of non-members are unspecified: untouched, or zero where a 16-byte store of four voxels holds a member)
+                assert n3 == n and np.array_equal(got3[mask], want[mask]) and np.all(np.isin(got3[~mask], (-7, 0) if n <= 4096 else (0,))), (shp, dens)
                 assert np.array_equal(b3, bbox) and np.array_equal(c3, cnt) and np.array_equal(s3, sums), (shp, dens)
                 d_l3.free()
             d_g.free(); d_lab.free()
+
+
+@pytest.mark.gpu
+def test_connected_components_several_colours_one_pass(pb3d_gpu, oracle):
+    """N colours in ONE labelling sequence (pb3d_label_colors_stats_dev) == N single-colour calls == the oracle's scipy numbering, per
+    colour: labels at the colour's voxels, component counts, boxes, voxel counts and coordinate sums.  Runs of different colours abut
+    without a gap (up to 64 segments per window), rows shorter / longer than a window, 1..8 colours, RGB grids and 1-byte label volumes."""
+    from pb3d import device as dev
+    from pb3d.voxel_carving_utils import _label_stats, _label_stats_multi
+    rng = np.random.default_rng(404)
+    pal = np.array([(200, 10, 30), (1, 220, 5), (63, 138, 173), (190, 0, 255), (0, 0, 255), (5, 223, 223), (255, 180, 80), (180, 140, 255),
+                    (255, 120, 230), (9, 9, 9)], np.uint8)
+    cases = [((1, 1, 1), 1, 1.0), ((4, 5, 63), 2, 0.5), ((6, 3, 128), 3, 0.9), ((7, 9, 129), 4, 0.3), ((9, 8, 191), 5, 1.0), ((12, 10, 200), 8, 0.7),
+             ((33, 17, 355), 4, 0.97), ((16, 16, 16), 8, 1.0), ((21, 22, 23), 2, 0.05), ((40, 2, 97), 7, 0.6), ((24, 20, 300), 4, 0.995)]
+    for shp, K, dens in cases:
+        for form in ("rgb", "label"):
+            # blocky colour field (runs of the same colour cross windows) with noise on top
+            idx = rng.integers(0, len(pal), tuple(max(1, (a + 5) // 6) for a in shp))
+            idx = idx.repeat(6, 0).repeat(6, 1).repeat(6, 2)[:shp[0], :shp[1], :shp[2]]
+            noise = rng.random(shp) > dens
+            idx[noise] = rng.integers(0, len(pal), int(noise.sum()))
+            if form == "rgb":
+                grid = np.ascontiguousarray(pal[idx]); cols = [pal[k] for k in range(K)]
+                masks = [np.all(grid == pal[k], axis=-1) for k in range(K)]
+            else:
+                grid = np.ascontiguousarray((idx + 1).astype(np.uint8)); cols = [int(k + 1) for k in range(K)]
+                masks = [grid == k + 1 for k in range(K)]
+            d_g = dev.from_numpy(grid)
+            d_lab = dev.from_numpy(np.full(shp, -7, np.int32))
+            res = _label_stats_multi(d_g, shp, cols, d_lab, cap=2048, members_only=True)
+            got = d_lab.download(shp, np.int32)
+            anym = np.zeros(shp, bool)
+            for k in range(K):
+                want, nw = oracle.label6(masks[k])
+                anym |= masks[k]
+                assert res[k] is not None and res[k][0] == nw, (shp, K, form, k)
+                assert np.array_equal(got[masks[k]], want[masks[k]]), (shp, K, form, k)
+                dev_l1 = dev.DeviceBuffer(int(np.prod(shp)) * 4)
+                n1, b1, c1, s1 = _label_stats(d_g, shp, cols[k] if form == "label" else np.ascontiguousarray(cols[k]), dev_l1, cap=2048)
+                assert n1 == nw and np.array_equal(dev_l1.download(shp, np.int32), want), (shp, K, form, k)
+                assert np.array_equal(res[k][1], b1) and np.array_equal(res[k][2], c1) and np.array_equal(res[k][3], s1), (shp, K, form, k)
+                assert np.array_equal(c1, np.bincount(want.ravel(), minlength=nw + 1)[1:]), (shp, K, form, k)
+                dev_l1.free()
+            assert np.all(np.isin(got[~anym], (-7, 0))), (shp, K, form)
+            # a full label volume of several colours: zeros wherever no requested colour sits
+            d_l2 = dev.from_numpy(np.full(shp, -7, np.int32))
+            res2 = _label_stats_multi(d_g, shp, cols, d_l2, cap=2048, members_only=False)
+            got2 = d_l2.download(shp, np.int32)
+            assert np.all(got2[~anym] == 0) and np.array_equal(got2[anym], got[anym]) and [r[0] for r in res2] == [r[0] for r in res], (shp, K, form)
+            # a capacity below a colour's component count: that colour comes back as None, the others stay valid
+            if max(r[0] for r in res) > 3:
+                res3 = _label_stats_multi(d_g, shp, cols, d_l2, cap=3, members_only=True)
+                for k in range(K):
+                    assert (res3[k] is None) == (res[k][0] > 3), (shp, K, form, k)
+                    if res3[k] is not None:
+                        assert np.array_equal(res3[k][1], res[k][1]) and np.array_equal(res3[k][2], res[k][2])
+            for b in (d_g, d_lab, d_l2):
+                b.free()
 
 
 def test_guided_carve_fused_component_loop(pb3d_gpu, oracle):
