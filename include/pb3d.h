@@ -65,6 +65,12 @@ int pb3d_dev_free(pb3d_ctx* ctx, void* dptr);
 int pb3d_dev_memset(pb3d_ctx* ctx, void* dptr, int value, size_t bytes);
 int pb3d_h2d(pb3d_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
 int pb3d_d2h(pb3d_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
+/* Host -> device without waiting: the bytes are copied into a pinned ring of the context first, so hptr may be reused when the call
+ * returns and the transfer is ordered on the context's stream like a kernel (inputs above 4 MiB take the blocking path of pb3d_h2d).
+ * What a resident pipeline uploads between its stages are 2-D masks and descriptors of a few hundred KB. */
+int pb3d_h2d_async(pb3d_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
+/* number of times the host has waited for the context's stream so far (tests bound the waits of a resident pipeline) */
+int64_t pb3d_sync_count(pb3d_ctx* ctx);
 int pb3d_d2d(pb3d_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* HIP events recorded on the context's stream (the stream every kernel is launched on). */
 int pb3d_event_create(pb3d_ctx* ctx, pb3d_event** ev);
@@ -312,6 +318,21 @@ int pb3d_guided_carve_dev(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_l
 int pb3d_guided_carve_color_dev(pb3d_ctx* ctx, uint8_t* d_grid, const int32_t* d_labels, int color_index, int channels, int64_t W, int64_t H,
                                 int64_t D, int64_t ncomp, const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off,
                                 int64_t mask_bytes, int angle_interval, int64_t* carved_counts, int* took);
+/* ... QUEUED: the call returns without waiting; the "carved voxels" counts are accumulated in d_counts (device memory, ncomp entries, cleared
+ * by the call) and every host argument may be reused on return (they are staged through pb3d_h2d_async's ring).  partwise_carve
+ * (reference :338-346) queues the component loops of all its parts behind ONE labelling and reads the counts once, at the end. */
+int pb3d_guided_carve_queue_dev(pb3d_ctx* ctx, uint8_t* d_grid, const int32_t* d_labels, int color_index, int channels, int64_t W, int64_t H,
+                                int64_t D, int64_t ncomp, const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off,
+                                int64_t mask_bytes, int angle_interval, int64_t* d_counts, int* took);
+/* recolor_backward_components (reference utils/voxel_carving_utils.py:252-266) on a resident grid WITHOUT a host round trip: the
+ * components of `color` are labelled (into d_labels, members only) with their statistics left on the device, the keep_k components with
+ * the smallest mean coordinate on sort_axis are kept (float64 means as np.mean gives them; equal means keep their numbering order, as
+ * the stable sorted() of :261 does), the others painted new_color -- all queued on the context's stream.  d_status (device, two int64,
+ * may be NULL): [0] = number of components, [1] = 1 when the device could not decide (more than 2048 components: nothing was painted;
+ * run pb3d_label_color_stats_dev + pb3d_recolor_last_labelled_dev instead).  channels = 3: colour grid; 1: label volume (color[0],
+ * new_color[0] are label values). */
+int pb3d_recolor_backward_dev(pb3d_ctx* ctx, uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3], const uint8_t new_color[3],
+                              int keep_k, int sort_axis, int channels, int32_t* d_labels, int64_t* d_status);
 /* The rest of the notebook-1 chain on the 1-byte LABEL form of a palette grid (row N3; label 0 = empty, the others index a palette):
  * the same kernels with one byte per voxel -- components of the voxels that carry `value`, the fused component loop, extrusion
  * (fill_label < 0: clear), recolouring and the output orientation.  Expanding a result with the palette gives the bytes of the RGB
@@ -325,6 +346,11 @@ int pb3d_label_values_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_
 int pb3d_guided_carve_label_dev(pb3d_ctx* ctx, uint8_t* d_grid_lab, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                                 const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
                                 int64_t* carved_counts, int* took);
+/* the per-component steps (crops too large for the fused loop) on a label volume */
+int pb3d_crop_occupancy_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
+                                  const int64_t hi[3], uint8_t* d_occ);
+int pb3d_component_paste_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
+                                   int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved);
 int pb3d_extrude_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t W, int64_t H, int64_t D, const uint8_t* d_valid, int64_t valid_w,
                            int axis, int plus, int depth, int fill_label, uint8_t* d_out);
 int pb3d_recolor_components_label_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,

@@ -13,7 +13,7 @@ int up(pb3d_ctx* ctx, int slot, const void* h, size_t bytes, void** d) {
 
 int down(pb3d_ctx* ctx, void* h, const void* d, size_t bytes) {
     if (bytes) PB3D_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     return PB3D_OK;
 }
 

@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void k_ccl_fold(int K, int dcap, const i64* __
 // Scratch slot 40: [header 64 B: i64 total[8]] [head: K x kFirst records] [final: K x dcap records] [shadow: kCopies x K x dcap records]
 static int label_colors_impl(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, const uint8_t* colors, int K, int C,
                              int32_t* d_labels, int64_t* ncomp, int64_t cap, bool members_only, int64_t* bbox_lo_hi, int64_t* count,
-                             int64_t* coord_sum, int* stats_valid) {
+                             int64_t* coord_sum, int* stats_valid, pb3d_ccl_dev* dev = nullptr) {
     PB3D_REQUIRE(ctx && colors && ncomp && A0 >= 0 && A1 >= 0 && A2 >= 0, "pb3d_label_color: bad argument");
     PB3D_REQUIRE(K >= 1 && K <= kMaxColors, "pb3d_label_colors: between 1 and %d colours per call (got %d)", kMaxColors, K);
     const i64 n = A0 * A1 * A2;
@@ -673,8 +673,8 @@ static int label_colors_impl(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, i
     if (n == 0) { if (stats_valid) for (int k = 0; k < K; ++k) stats_valid[k] = 1; return PB3D_OK; }
     PB3D_REQUIRE(n < (1ll << 31), "pb3d_label_color: grid too large for 32-bit labels");
     PB3D_REQUIRE(d_grid && d_labels, "pb3d_label_color: null buffer");
-    const bool stats = stats_valid != nullptr && cap > 0;
-    if (stats) PB3D_REQUIRE(bbox_lo_hi && count && coord_sum, "pb3d_label_color_stats: null output");
+    const bool stats = (stats_valid != nullptr || dev != nullptr) && cap > 0;
+    if (stats && !dev) PB3D_REQUIRE(bbox_lo_hi && count && coord_sum, "pb3d_label_color_stats: null output");
     CclColors cols;
     for (int k = 0; k < kMaxColors; ++k) cols.c[k] = 0xffffffffu;
     for (int k = 0; k < K; ++k) {
@@ -766,21 +766,25 @@ static int label_colors_impl(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, i
         hipLaunchKernelGGL(k_ccl_fold, dim3((unsigned)((dcap + 3) / 4 < 64 ? (dcap + 3) / 4 : 64), (unsigned)K), dim3(256), 0, ctx->stream, K, dcap, (const i64*)total, (const char*)shadow, fin, head, ncopies);
         PB3D_CHECK_LAUNCH();
     }
-    // the component counts and -- optimistically -- the statistics of the first kFirst components of every colour come back in ONE copy
-    struct Rec { int bb[8]; unsigned long long cs[4]; };
-    static_assert(sizeof(Rec) == 64, "the statistics block is 64-byte records");
-    char* hb = (char*)ctx->pinned + 1024;
-    static_assert(64 + (size_t)kMaxColors * kFirst * 64 + 1024 + 64 <= (1 << 16), "the pinned area holds the read-back block");
-    PB3D_HIP(hipMemcpyAsync(hb, sblk, stats ? head_bytes : 64, hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
-    const i64* nroots = (const i64*)hb;
-    for (int k = 0; k < K; ++k) ncomp[k] = nroots[k];
     // the membership bits of THIS label volume stay where they are: consumers that only need the members' labels (the component loop,
     // the recolouring) walk the 1-bit-per-voxel arrays instead of the 4-byte-per-voxel one
     pb3d_ctx::CclLast& cl = ctx->ccl_last;
     cl.valid = true; cl.labels = d_labels; cl.bits = bits; cl.rows = rows; cl.A2 = A2; cl.P = P; cl.gen = ctx->scratch_slot_gen[42];
     cl.members_only = members_only; cl.K = K; cl.C = C;
     for (int k = 0; k < kMaxColors; ++k) cl.colors[k] = cols.c[k];
+    if (dev) {          // a consumer on the device (pb3d_recolor_backward_dev): counts and records stay there, no host wait
+        dev->total = total; dev->records = fin; dev->dcap = dcap;
+        return PB3D_OK;
+    }
+    // the component counts and -- optimistically -- the statistics of the first kFirst components of every colour come back in ONE copy
+    struct Rec { int bb[8]; unsigned long long cs[4]; };
+    static_assert(sizeof(Rec) == 64, "the statistics block is 64-byte records");
+    char* hb = (char*)ctx->pinned + 1024;
+    static_assert(64 + (size_t)kMaxColors * kFirst * 64 + 1024 + 64 <= (1 << 16), "the pinned area holds the read-back block");
+    PB3D_HIP(hipMemcpyAsync(hb, sblk, stats ? head_bytes : 64, hipMemcpyDeviceToHost, ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
+    const i64* nroots = (const i64*)hb;
+    for (int k = 0; k < K; ++k) ncomp[k] = nroots[k];
     if (stats) {
         for (int k = 0; k < K; ++k) {
             if (nroots[k] > dcap) continue;
@@ -798,7 +802,7 @@ static int label_colors_impl(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, i
             if (nroots[k] > n0) {
                 std::vector<Rec> more((size_t)(nroots[k] - n0));
                 PB3D_HIP(hipMemcpyAsync(more.data(), fin + ((size_t)k * (size_t)dcap + (size_t)n0) * 64, more.size() * sizeof(Rec), hipMemcpyDeviceToHost, ctx->stream));
-                PB3D_HIP(hipStreamSynchronize(ctx->stream));
+                PB3D_TRY(pb3d_stream_sync(ctx));
                 for (i64 c = n0; c < nroots[k]; ++c) put(c, more[(size_t)(c - n0)]);
             }
             stats_valid[k] = 1;
@@ -840,4 +844,11 @@ extern "C" int pb3d_label_values_stats_dev(pb3d_ctx* ctx, const uint8_t* d_grid_
                                            int64_t* count, int64_t* coord_sum, int* stats_valid) {
     PB3D_REQUIRE(stats_valid != nullptr, "pb3d_label_values_stats: null output");
     return label_colors_impl(ctx, d_grid_lab, A0, A1, A2, values, nvalues, 1, d_labels, ncomp, cap, members_only != 0, bbox_lo_hi, count, coord_sum, stats_valid);
+}
+
+// labelling + statistics of ONE colour with everything left on the device (csrc/components.hip: pb3d_recolor_backward_dev)
+int pb3d_ccl_label_on_device(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3], int channels, int32_t* d_labels,
+                             int64_t cap, pb3d_ccl_dev* dev) {
+    int64_t ncomp = 0;
+    return label_colors_impl(ctx, d_grid, A0, A1, A2, color, 1, channels, d_labels, &ncomp, cap, true, nullptr, nullptr, nullptr, nullptr, dev);
 }

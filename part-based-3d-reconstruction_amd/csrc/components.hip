@@ -86,13 +86,14 @@ __global__ __launch_bounds__(256) void k_comp_stats(const int* __restrict__ labe
 }
 
 // occupancy of the bbox crop of a colour grid: occ[xs,ys,zs] = any(grid[x0+xs, y0+ys, z0+zs, :] > 0)
+// (C = 1: the grid is a 1-byte label volume)
 __global__ __launch_bounds__(256) void k_crop_occ(const u8* __restrict__ grid, i64 A1, i64 A2, i64 x0, i64 y0, i64 z0, i64 Wc, i64 Hc,
-                                                  i64 Dc, u8* __restrict__ occ) {
+                                                  i64 Dc, u8* __restrict__ occ, int C) {
     const i64 n = Wc * Hc * Dc;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         const i64 zs = i % Dc, r = i / Dc, ys = r % Hc, xs = r / Hc;
-        const u8* p = grid + (((x0 + xs) * A1 + (y0 + ys)) * A2 + (z0 + zs)) * 3;
-        occ[i] = (p[0] | p[1] | p[2]) ? 1 : 0;
+        const u8* p = grid + (((x0 + xs) * A1 + (y0 + ys)) * A2 + (z0 + zs)) * C;
+        occ[i] = (C == 1 ? p[0] : (p[0] | p[1] | p[2])) ? 1 : 0;
     }
 }
 
@@ -100,11 +101,17 @@ __global__ __launch_bounds__(256) void k_crop_occ(const u8* __restrict__ grid, i
 //   carved[v] = 0 where labels[v] == id ; then carved[v] = colored[v] where carved_occ && colored[v] != 0
 __global__ __launch_bounds__(256) void k_comp_paste(const u8* __restrict__ colored, const int* __restrict__ labels, int id,
                                                     const u8* __restrict__ carved_occ, i64 A1, i64 A2, i64 x0, i64 y0, i64 z0, i64 Wc,
-                                                    i64 Hc, i64 Dc, u8* __restrict__ carved) {
+                                                    i64 Hc, i64 Dc, u8* __restrict__ carved, int C) {
     const i64 n = Wc * Hc * Dc;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         const i64 zs = i % Dc, r = i / Dc, ys = r % Hc, xs = r / Hc;
         const i64 v = ((x0 + xs) * A1 + (y0 + ys)) * A2 + (z0 + zs);
+        if (C == 1) {       // label volume: one byte per voxel
+            const u8 c = colored[v];
+            if (carved_occ[i] && c) carved[v] = (u8)(c * carved_occ[i]);
+            else if (labels[v] == id) carved[v] = 0;
+            continue;
+        }
         const u8 c0 = colored[3 * v], c1 = colored[3 * v + 1], c2 = colored[3 * v + 2];
         // subgrid * carved_occ in uint8 (carved_occ is 0/1 here): non-zero iff both are
         if (carved_occ[i] && (c0 | c1 | c2)) {
@@ -135,7 +142,7 @@ __device__ __forceinline__ u64 rl64(u64 v, int l) {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)v, l);
 }
 __global__ __launch_bounds__(256) void k_recolor_bits(const u64* __restrict__ bits, const int* __restrict__ labels, const u8* __restrict__ comp_flag,
-                                                      i64 nwords, pb3d_magic mP, int A2, u8 r, u8 g, u8 b, u8* __restrict__ grid, int C) {
+                                                      i64 nwords, pb3d_magic mP, int A2, u8 r, u8 g, u8 b, u8* __restrict__ grid, int C, int nflag) {
     const int lane = threadIdx.x & 63;
     const i64 nwaves = (i64)gridDim.x * 4, wid = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (i64 c0 = wid * 64; c0 < nwords; c0 += nwaves * 64) {
@@ -151,11 +158,38 @@ __global__ __launch_bounds__(256) void k_recolor_bits(const u64* __restrict__ bi
             const u32 row = pb3d_div(widx, mP), t = widx - row * mP.d;
             const i64 v = (i64)row * A2 + 64 * (i64)t + lane;
             const int L = labels[v];
-            if (L > 0 && comp_flag[L - 1]) {
+            if (L > 0 && L <= nflag && comp_flag[L - 1]) {        // (labels beyond the flag array: not decided here, not painted)
                 if (C == 1) grid[v] = r;
                 else { grid[3 * v] = r; grid[3 * v + 1] = g; grid[3 * v + 2] = b; }
             }
         }
+    }
+}
+
+// recolor_backward_components without the host (reference :256-265): the k components with the smallest mean coordinate on sort_axis
+// are kept -- sorted() is stable, so equal means keep their numbering order -- the others flagged.  One workgroup: component i's rank is
+// the number of components that sort before it.  means = float64 sum / float64 count, as np.mean of the int64 column gives them.
+// status[0] = number of components, status[1] = 1 when there are more than the records hold (nothing is flagged then: the caller's
+// host path decides).
+constexpr int kRecolorDeviceMax = 2048;
+__global__ __launch_bounds__(1024) void k_recolor_select(const i64* __restrict__ total, const char* __restrict__ records, int dcap, int keep_k, int axis,
+                                                         u8* __restrict__ flags, i64* __restrict__ status) {
+    __shared__ double mean[kRecolorDeviceMax];
+    const i64 n = total[0];
+    const bool over = n > dcap || n > kRecolorDeviceMax;
+    if (threadIdx.x == 0 && status) { status[0] = n; status[1] = over ? 1 : 0; }
+    const int m = over ? 0 : (int)n;
+    for (int i = (int)threadIdx.x; i < dcap; i += (int)blockDim.x) flags[i] = 0;
+    for (int i = (int)threadIdx.x; i < m; i += (int)blockDim.x) {
+        const unsigned long long* cs = (const unsigned long long*)(records + (i64)i * 64 + 32);
+        mean[i] = (double)(long long)cs[1 + axis] / (double)(long long)cs[0];
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < m; i += (int)blockDim.x) {
+        const double mi = mean[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (mean[j] < mi) || (mean[j] == mi && j < i);
+        flags[i] = rank >= keep_k ? 1 : 0;
     }
 }
 
@@ -421,7 +455,7 @@ int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0,
     if (!hbb || !hcs) { free(hbb); free(hcs); pb3d_set_error("pb3d_component_stats: out of host memory"); return PB3D_ENOMEM; }
     hipError_t e = hipMemcpyAsync(hbb, bb, (size_t)ncomp * 6 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hcs, cs, (size_t)ncomp * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) { e = hipStreamSynchronize(ctx->stream); ++ctx->sync_count; }
     if (e == hipSuccess)
         for (i64 k = 0; k < ncomp; ++k) {
             for (int a = 0; a < 3; ++a) { bbox_lo_hi[6 * k + a] = hbb[6 * k + a]; bbox_lo_hi[6 * k + 3 + a] = (i64)hbb[6 * k + 3 + a] + 1; }
@@ -433,22 +467,32 @@ int pb3d_component_stats_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t A0,
     return PB3D_OK;
 }
 
-int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
-                            const int64_t hi[3], uint8_t* d_occ) {
+static int crop_occupancy_impl(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3],
+                               uint8_t* d_occ, int C) {
     PB3D_REQUIRE(ctx && lo && hi, "pb3d_crop_occupancy: bad argument");
     const i64 Wc = hi[0] - lo[0], Hc = hi[1] - lo[1], Dc = hi[2] - lo[2];
     PB3D_REQUIRE(lo[0] >= 0 && lo[1] >= 0 && lo[2] >= 0 && hi[0] <= A0 && hi[1] <= A1 && hi[2] <= A2 && Wc >= 0 && Hc >= 0 && Dc >= 0,
                  "pb3d_crop_occupancy: box outside the grid");
     if (Wc * Hc * Dc == 0) return PB3D_OK;
-    PB3D_REQUIRE(d_grid_rgb && d_occ, "pb3d_crop_occupancy: null buffer");
-    hipLaunchKernelGGL(k_crop_occ, dim3(pb3d_stream_blocks(ctx, Wc * Hc * Dc, 256, 8)), dim3(256), 0, ctx->stream, d_grid_rgb, A1, A2, lo[0],
-                       lo[1], lo[2], Wc, Hc, Dc, d_occ);
+    PB3D_REQUIRE(d_grid && d_occ, "pb3d_crop_occupancy: null buffer");
+    hipLaunchKernelGGL(k_crop_occ, dim3(pb3d_stream_blocks(ctx, Wc * Hc * Dc, 256, 8)), dim3(256), 0, ctx->stream, d_grid, A1, A2, lo[0],
+                       lo[1], lo[2], Wc, Hc, Dc, d_occ, C);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
 }
 
-int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
-                             int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved) {
+int pb3d_crop_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
+                            const int64_t hi[3], uint8_t* d_occ) {
+    return crop_occupancy_impl(ctx, d_grid_rgb, A0, A1, A2, lo, hi, d_occ, 3);
+}
+
+int pb3d_crop_occupancy_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3],
+                                  const int64_t hi[3], uint8_t* d_occ) {
+    return crop_occupancy_impl(ctx, d_grid_lab, A0, A1, A2, lo, hi, d_occ, 1);
+}
+
+static int component_paste_impl(pb3d_ctx* ctx, const uint8_t* d_colored, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
+                                int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved, int C) {
     PB3D_REQUIRE(ctx && lo && hi, "pb3d_component_paste: bad argument");
     const i64 Wc = hi[0] - lo[0], Hc = hi[1] - lo[1], Dc = hi[2] - lo[2];
     PB3D_REQUIRE(lo[0] >= 0 && lo[1] >= 0 && lo[2] >= 0 && hi[0] <= A0 && hi[1] <= A1 && hi[2] <= A2 && Wc >= 0 && Hc >= 0 && Dc >= 0,
@@ -456,9 +500,19 @@ int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int3
     if (Wc * Hc * Dc == 0) return PB3D_OK;
     PB3D_REQUIRE(d_colored && d_labels && d_carved_occ && d_carved, "pb3d_component_paste: null buffer");
     hipLaunchKernelGGL(k_comp_paste, dim3(pb3d_stream_blocks(ctx, Wc * Hc * Dc, 256, 8)), dim3(256), 0, ctx->stream, d_colored, d_labels, id,
-                       d_carved_occ, A1, A2, lo[0], lo[1], lo[2], Wc, Hc, Dc, d_carved);
+                       d_carved_occ, A1, A2, lo[0], lo[1], lo[2], Wc, Hc, Dc, d_carved, C);
     PB3D_CHECK_LAUNCH();
     return PB3D_OK;
+}
+
+int pb3d_component_paste_dev(pb3d_ctx* ctx, const uint8_t* d_colored, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
+                             int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved) {
+    return component_paste_impl(ctx, d_colored, d_labels, id, d_carved_occ, A0, A1, A2, lo, hi, d_carved, 3);
+}
+
+int pb3d_component_paste_label_dev(pb3d_ctx* ctx, const uint8_t* d_grid_lab, const int32_t* d_labels, int32_t id, const uint8_t* d_carved_occ,
+                                   int64_t A0, int64_t A1, int64_t A2, const int64_t lo[3], const int64_t hi[3], uint8_t* d_carved) {
+    return component_paste_impl(ctx, d_grid_lab, d_labels, id, d_carved_occ, A0, A1, A2, lo, hi, d_carved, 1);
 }
 
 static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,
@@ -468,8 +522,7 @@ static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, co
     PB3D_REQUIRE(d_labels && comp_flag && d_grid_rgb, "pb3d_recolor_components: null buffer");
     void* f;
     PB3D_TRY(pb3d_scratch(ctx, 6, (size_t)ncomp, &f));
-    PB3D_HIP(hipMemcpyAsync(f, comp_flag, (size_t)ncomp, hipMemcpyHostToDevice, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));   // comp_flag is a caller-owned host buffer
+    PB3D_TRY(pb3d_h2d_async(ctx, f, comp_flag, (size_t)ncomp));      // (comp_flag is a caller-owned host buffer: staged, no wait)
     const pb3d_ctx::CclLast& cl = ctx->ccl_last;
     const bool bits_ok = cl.valid && cl.labels == (const void*)d_labels && cl.rows * cl.A2 == nvox && cl.gen == ctx->scratch_slot_gen[42] &&
                          cl.rows * cl.P < (1ll << 32) && cl.K == 1;
@@ -477,7 +530,8 @@ static int recolor_impl(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, co
     if (last_labelled) {
         const i64 nwords = cl.rows * cl.P;
         hipLaunchKernelGGL(k_recolor_bits, dim3(pb3d_stream_blocks(ctx, (nwords + 63) / 64, 4, 8)), dim3(256), 0, ctx->stream, (const u64*)cl.bits, d_labels,
-                           (const u8*)f, nwords, pb3d_make_magic((u32)cl.P), (int)cl.A2, new_color[0], new_color[1], new_color[2], d_grid_rgb, C);
+                           (const u8*)f, nwords, pb3d_make_magic((u32)cl.P), (int)cl.A2, new_color[0], new_color[1], new_color[2], d_grid_rgb, C,
+                           (int)(ncomp < 0x7fffffff ? ncomp : 0x7fffffff));
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     }
@@ -496,6 +550,36 @@ int pb3d_recolor_last_labelled_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64
                                    const uint8_t new_color[3], uint8_t* d_grid, int channels) {
     PB3D_REQUIRE(channels == 1 || channels == 3, "pb3d_recolor_last_labelled: channels is 1 (labels) or 3 (colours)");
     return recolor_impl(ctx, d_labels, nvox, comp_flag, ncomp, new_color, d_grid, channels, true);
+}
+
+// recolor_backward_components (reference utils/voxel_carving_utils.py:252-266) on a resident grid WITHOUT a host round trip: labelling
+// for the members only with the statistics left on the device, the keep decision by one workgroup, the recolouring over the membership
+// bits -- everything queued on the context's stream.
+int pb3d_recolor_backward_dev(pb3d_ctx* ctx, uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3], const uint8_t new_color[3],
+                              int keep_k, int sort_axis, int channels, int32_t* d_labels, int64_t* d_status) {
+    PB3D_REQUIRE(ctx && color && new_color && A0 >= 0 && A1 >= 0 && A2 >= 0, "pb3d_recolor_backward: bad argument");
+    PB3D_REQUIRE(channels == 1 || channels == 3, "pb3d_recolor_backward: channels is 1 (labels) or 3 (colours)");
+    PB3D_REQUIRE(sort_axis >= 0 && sort_axis <= 2, "pb3d_recolor_backward: sort_axis is 0, 1 or 2");
+    const i64 nvox = A0 * A1 * A2;
+    if (nvox == 0) {
+        if (d_status) PB3D_HIP(hipMemsetAsync(d_status, 0, 16, ctx->stream));
+        return PB3D_OK;
+    }
+    PB3D_REQUIRE(d_grid && d_labels, "pb3d_recolor_backward: null buffer");
+    pb3d_ccl_dev dev;
+    PB3D_TRY(pb3d_ccl_label_on_device(ctx, d_grid, A0, A1, A2, color, channels, d_labels, kRecolorDeviceMax, &dev));
+    void* f;
+    PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)dev.dcap, &f));
+    hipLaunchKernelGGL(k_recolor_select, dim3(1), dim3(1024), 0, ctx->stream, dev.total, dev.records, dev.dcap, keep_k < 0 ? 0 : keep_k, sort_axis, (u8*)f,
+                       (i64*)d_status);
+    PB3D_CHECK_LAUNCH();
+    const pb3d_ctx::CclLast& cl = ctx->ccl_last;
+    PB3D_REQUIRE(cl.valid && cl.rows * cl.P < (1ll << 32), "pb3d_recolor_backward: grid too large");
+    const i64 nwords = cl.rows * cl.P;
+    hipLaunchKernelGGL(k_recolor_bits, dim3(pb3d_stream_blocks(ctx, (nwords + 63) / 64, 4, 8)), dim3(256), 0, ctx->stream, (const u64*)cl.bits, d_labels,
+                       (const u8*)f, nwords, pb3d_make_magic((u32)cl.P), (int)cl.A2, new_color[0], new_color[1], new_color[2], d_grid, channels, dev.dcap);
+    PB3D_CHECK_LAUNCH();
+    return PB3D_OK;
 }
 
 int pb3d_recolor_components_label_dev(pb3d_ctx* ctx, const int32_t* d_labels, int64_t nvox, const uint8_t* comp_flag, int64_t ncomp,

@@ -17,7 +17,10 @@ void pb3d_set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int pb3d_version(void) { return 100; }
+int pb3d_version(void) { return 101; }
+
+// number of host waits on the context's stream so far (development / tests: a resident pipeline is meant to wait a bounded number of times)
+int64_t pb3d_sync_count(pb3d_ctx* ctx) { return ctx ? (int64_t)ctx->sync_count : -1; }
 
 const char* pb3d_last_error(void) { return g_err; }
 
@@ -153,6 +156,7 @@ void pb3d_destroy(pb3d_ctx* ctx) {
     for (int i = 0; i < PB3D_NSCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(ctx->rot_cache[k].ready); (void)hipEventDestroy(ctx->rot_cache[k].used); }
     (void)hipEventDestroy(ctx->s32_ev);
     (void)hipStreamDestroy(ctx->aux_stream);
@@ -174,8 +178,7 @@ int pb3d_device_info(pb3d_ctx* ctx, char* name, int name_cap, int* compute_units
 
 int pb3d_sync(pb3d_ctx* ctx) {
     PB3D_REQUIRE(ctx != nullptr, "pb3d_sync: null context");
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
-    return PB3D_OK;
+    return pb3d_stream_sync(ctx);
 }
 
 // give every cached device block back to the driver (when a hipMalloc fails, and at destroy)
@@ -240,7 +243,7 @@ int pb3d_dev_free(pb3d_ctx* ctx, void* dptr) {
             int old = 0;
             for (int i = 1; i < ctx->pool_nfree; ++i)
                 if (ctx->pool_free[i].stamp < ctx->pool_free[old].stamp) old = i;
-            PB3D_HIP(hipStreamSynchronize(ctx->stream));
+            PB3D_TRY(pb3d_stream_sync(ctx));
             PB3D_HIP(hipFree(ctx->pool_free[old].p));
             ctx->pool_cached -= ctx->pool_free[old].bytes;
             ctx->pool_free[old] = ctx->pool_free[--ctx->pool_nfree];
@@ -249,7 +252,7 @@ int pb3d_dev_free(pb3d_ctx* ctx, void* dptr) {
         ctx->pool_cached += bytes;
         return PB3D_OK;
     }
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     PB3D_HIP(hipFree(dptr));
     return PB3D_OK;
 }
@@ -265,7 +268,29 @@ int pb3d_h2d(pb3d_ctx* ctx, void* dptr, const void* hptr, size_t bytes) {
     if (!bytes) return PB3D_OK;
     PB3D_REQUIRE(dptr && hptr, "pb3d_h2d: null buffer");
     PB3D_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    return pb3d_stream_sync(ctx);
+}
+
+// Host -> device WITHOUT waiting: the bytes are copied into a pinned ring first, so the caller's buffer is free again when the call returns
+// and the copy itself is ordered on the context's stream like a kernel.  Inputs larger than half the ring take the blocking path.
+int pb3d_h2d_async(pb3d_ctx* ctx, void* dptr, const void* hptr, size_t bytes) {
+    PB3D_REQUIRE(ctx != nullptr, "pb3d_h2d_async: null context");
+    if (!bytes) return PB3D_OK;
+    PB3D_REQUIRE(dptr && hptr, "pb3d_h2d_async: null buffer");
+    if (!ctx->stage) {
+        const size_t ring = (size_t)8 << 20;
+        PB3D_HIP(hipHostMalloc(&ctx->stage, ring, hipHostMallocDefault));
+        ctx->stage_bytes = ring; ctx->stage_head = 0;
+    }
+    if (bytes > ctx->stage_bytes / 2) return pb3d_h2d(ctx, dptr, hptr, bytes);
+    size_t head = (ctx->stage_head + 63) & ~(size_t)63;
+    if (head + bytes > ctx->stage_bytes) {        // the ring is full: everything staged so far must have left it
+        PB3D_TRY(pb3d_stream_sync(ctx));
+        head = 0;
+    }
+    memcpy((char*)ctx->stage + head, hptr, bytes);
+    PB3D_HIP(hipMemcpyAsync(dptr, (char*)ctx->stage + head, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->stage_head = head + bytes;
     return PB3D_OK;
 }
 
@@ -274,8 +299,7 @@ int pb3d_d2h(pb3d_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
     if (!bytes) return PB3D_OK;
     PB3D_REQUIRE(dptr && hptr, "pb3d_d2h: null buffer");
     PB3D_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
-    return PB3D_OK;
+    return pb3d_stream_sync(ctx);
 }
 
 int pb3d_d2d(pb3d_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -349,11 +373,18 @@ int pb3d_offset(const double M[9], const int64_t shape[3], double off[3]) {
 
 }  // extern "C"
 
+int pb3d_stream_sync(pb3d_ctx* ctx) {
+    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stage_head = 0;
+    ++ctx->sync_count;
+    return PB3D_OK;
+}
+
 int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
     PB3D_REQUIRE(ctx != nullptr && slot >= 0 && slot < PB3D_NSCRATCH, "pb3d_scratch: bad slot");
     if (ctx->scratch_bytes[slot] < bytes || !ctx->scratch[slot]) {
         if (ctx->scratch[slot]) {
-            PB3D_HIP(hipStreamSynchronize(ctx->stream));
+            PB3D_TRY(pb3d_stream_sync(ctx));
             PB3D_HIP(hipStreamSynchronize(ctx->aux_stream));
             PB3D_HIP(hipFree(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;

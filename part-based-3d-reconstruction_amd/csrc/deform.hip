@@ -171,7 +171,7 @@ int centers(pb3d_ctx* ctx, const float* d_pts, i64 n, double sxz, double sy, dou
                        (unsigned long long*)acc);
     PB3D_CHECK_LAUNCH();
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, acc, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     const long long* h = (const long long*)ctx->pinned;
     if (h[3] != 0) {
         pb3d_set_error("pb3d_deform: %lld point coordinates are not voxel indices (integer-valued, |v| < 2^22)", h[3]);
@@ -209,7 +209,7 @@ int pb3d_deform_count_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, double s
     hipLaunchKernelGGL(k_deform_bbox, dim3(blocks), dim3(256), 0, ctx->stream, d_pts, n, P, (int*)bbv);
     PB3D_CHECK_LAUNCH();
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, bbv, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     const int* bb = (const int*)ctx->pinned;
     if (bb[6]) {
         pb3d_set_error("pb3d_deform: deformed coordinates exceed +-2^30");
@@ -273,7 +273,7 @@ int pb3d_scatter_colors_dev(pb3d_ctx* ctx, const int64_t* d_coords, const uint8_
                        d_cols, m, A0, A1, A2, d_grid, (int*)flag);
     PB3D_CHECK_LAUNCH();
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     if (*(const int*)ctx->pinned) {
         pb3d_set_error("index out of bounds in pb3d_scatter_colors (NumPy would raise IndexError)");
         return PB3D_EINVAL;
@@ -335,7 +335,7 @@ int pb3d_deform_iou_batch_dev(pb3d_ctx* ctx, const float* d_pts, int64_t n, cons
                            color[1], color[2], d_counts);
         hipok(hipGetLastError(), "k_deform_iou_batch");
         hipok(hipMemcpyAsync(hc, cnt, (size_t)kn * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
-        hipok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        ++ctx->sync_count; hipok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
         if (rc != PB3D_OK) break;
         for (i64 k = 0; k < kn; ++k) { inter[k0 + k] = (int64_t)hc[2 * k]; uni[k0 + k] = (int64_t)hc[2 * k + 1]; nvalid[k0 + k] = (int64_t)hc[2 * kn + k]; }
     }
@@ -364,7 +364,7 @@ int pb3d_deform_fill(pb3d_ctx* ctx, int64_t n_unique, int64_t* coords) {
     PB3D_TRY(pb3d_scratch(ctx, 1, (size_t)n_unique * 3 * sizeof(i64), &d));
     PB3D_TRY(pb3d_deform_fill_dev(ctx, n_unique, (int64_t*)d));
     PB3D_HIP(hipMemcpyAsync(coords, d, (size_t)n_unique * 3 * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     return PB3D_OK;
 }
 

@@ -199,12 +199,13 @@ static bool boxes_overlap(const i64* a, const i64* b) {
 
 static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* d_labels, int64_t W, int64_t H, int64_t D, int64_t ncomp,
                              const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off, int64_t mask_bytes, int angle_interval,
-                             int64_t* carved_counts, int* took, int C, int color_index) {
+                             int64_t* carved_counts, int* took, int C, int color_index, int64_t* d_counts_out = nullptr) {
     PB3D_REQUIRE(ctx && took && W >= 0 && H >= 0 && D >= 0 && ncomp >= 0, "pb3d_guided_carve: bad argument");
     *took = 0;
     PB3D_REQUIRE(angle_interval > 0, "pb3d_guided_carve: angle_interval must be a positive integer (got %d)", angle_interval);
     if (ncomp == 0 || W * H * D == 0) { *took = 1; return PB3D_OK; }
-    PB3D_REQUIRE(d_grid_rgb && d_labels && bbox_lo_hi && masks && mask_off && carved_counts, "pb3d_guided_carve: null buffer");
+    PB3D_REQUIRE(d_grid_rgb && d_labels && bbox_lo_hi && masks && mask_off && (carved_counts || d_counts_out), "pb3d_guided_carve: null buffer");
+    const bool queued = d_counts_out != nullptr;          // the counts stay on the device, the call does not wait
     const int nrot = 90 / angle_interval;                 // len(range(0, 91, k)) - 1 rotation steps after the 0-degree carve
     // every crop's 32-plane slice (two buffers + mask bits) must fit the LDS and its offsets 16 bits: otherwise the caller's loop
     size_t lds_max = 0;
@@ -238,8 +239,10 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
     const size_t nvox3 = (size_t)(W * H * D) * (size_t)C;
     void *d_masks, *d_counts;
     PB3D_TRY(pb3d_scratch(ctx, 37, (size_t)mask_bytes + 16, &d_masks));
-    PB3D_TRY(pb3d_scratch(ctx, 39, (size_t)ncomp * sizeof(unsigned long long), &d_counts));
-    PB3D_HIP(hipMemcpyAsync(d_masks, masks, (size_t)mask_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (queued) d_counts = d_counts_out;
+    else PB3D_TRY(pb3d_scratch(ctx, 39, (size_t)ncomp * sizeof(unsigned long long), &d_counts));
+    // every host input goes through the context's pinned staging ring: the caller's buffers are free when the call returns
+    PB3D_TRY(pb3d_h2d_async(ctx, d_masks, masks, (size_t)mask_bytes));
     PB3D_HIP(hipMemsetAsync(d_counts, 0, (size_t)ncomp * sizeof(unsigned long long), ctx->stream));
     // batches: consecutive components with pairwise disjoint boxes, at most kBatch of them (descriptor upload size)
     const int kBatch = 48;
@@ -328,7 +331,7 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
             for (const RotParams& rp : ps) { CropDesc as; memcpy(&as, &rp, sizeof(as)); ds.push_back(as); }     // [descriptors | parameters]
             CropDesc* ddb = (CropDesc*)((char*)dd + slice * bi);
             RotParams* dpb = (RotParams*)(ddb + nd);
-            PB3D_HIP(hipMemcpyAsync(ddb, ds.data(), ds.size() * sizeof(CropDesc), hipMemcpyHostToDevice, ctx->stream));
+            PB3D_TRY(pb3d_h2d_async(ctx, ddb, ds.data(), ds.size() * sizeof(CropDesc)));
             const int n = (int)(e - a);
             if (nrot > 0) {
                 dim3 gridc((unsigned)std::min((maxcells + 255) / 256, 64), (unsigned)(n * nrot));
@@ -343,11 +346,19 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");
-        PB3D_HIP(hipMemcpyAsync(carved_counts, d_counts, (size_t)ncomp * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (!queued) PB3D_HIP(hipMemcpyAsync(carved_counts, d_counts, (size_t)ncomp * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         return PB3D_OK;
     };
     rc = run();
-    hipError_t es = hipStreamSynchronize(ctx->stream);          // the counts are the caller's (the printed log); the staging vectors die here
+    if (queued) {
+        // (a block handed back to the pool is only ever given to later work on the same stream, in order)
+        if (copy) (void)pb3d_dev_free(ctx, copy);
+        if (rc != PB3D_OK) return rc;
+        *took = 1;
+        return PB3D_OK;
+    }
+    ++ctx->sync_count;
+    hipError_t es = hipStreamSynchronize(ctx->stream);          // the counts are the caller's (the printed log)
     if (copy) (void)pb3d_dev_free(ctx, copy);
     if (rc != PB3D_OK) return rc;
     PB3D_HIP(es);
@@ -371,6 +382,17 @@ int pb3d_guided_carve_color_dev(pb3d_ctx* ctx, uint8_t* d_grid, const int32_t* d
     PB3D_REQUIRE(ctx && color_index >= 0 && color_index < PB3D_CCL_MAX_COLORS, "pb3d_guided_carve_color: bad colour index");
     return guided_carve_impl(ctx, d_grid, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, carved_counts, took, channels,
                              color_index);
+}
+
+// ... QUEUED: the call returns without waiting, the "carved voxels" counts are accumulated in d_counts (device, ncomp entries, cleared by
+// the call); every host argument may be reused on return
+int pb3d_guided_carve_queue_dev(pb3d_ctx* ctx, uint8_t* d_grid, const int32_t* d_labels, int color_index, int channels, int64_t W, int64_t H,
+                                int64_t D, int64_t ncomp, const int64_t* bbox_lo_hi, const uint8_t* masks, const int64_t* mask_off,
+                                int64_t mask_bytes, int angle_interval, int64_t* d_counts, int* took) {
+    PB3D_REQUIRE(channels == 1 || channels == 3, "pb3d_guided_carve_queue: channels is 1 (labels) or 3 (colours)");
+    PB3D_REQUIRE(ctx && color_index >= 0 && color_index < PB3D_CCL_MAX_COLORS && d_counts, "pb3d_guided_carve_queue: bad argument");
+    return guided_carve_impl(ctx, d_grid, d_labels, W, H, D, ncomp, bbox_lo_hi, masks, mask_off, mask_bytes, angle_interval, nullptr, took, channels,
+                             color_index, d_counts);
 }
 
 // the same on a 1-byte LABEL volume (row N3): occupancy = label != 0, cleared voxels get label 0

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_label_final(const u8* __restrict__ labe
 
 int read_flag(pb3d_ctx* ctx, const int* d_flag, int* out) {
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     *out = *(const int*)ctx->pinned;
     return PB3D_OK;
 }

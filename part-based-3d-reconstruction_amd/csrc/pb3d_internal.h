@@ -50,6 +50,10 @@ struct pb3d_ctx {
     // small pinned host area for counters read back from the device
     void* pinned;
     size_t pinned_bytes;
+    // pinned staging ring of pb3d_h2d_async: small host inputs (2-D masks, descriptors) go up without a host wait
+    void* stage;
+    size_t stage_bytes, stage_head;
+    u64 sync_count;             // host waits on the context's stream so far (pb3d_sync_count: tests bound the waits of a pipeline)
     // state kept between pb3d_points_count and pb3d_points_fill (host-pointer flavour)
     struct {
         i64 A0, A1, A2, n;
@@ -140,6 +144,8 @@ void pb3d_set_error(const char* fmt, ...);
 
 // scratch slot `slot` grown to at least `bytes`
 int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out);
+// hipStreamSynchronize(ctx->stream) + bookkeeping (the staging ring is empty afterwards)
+int pb3d_stream_sync(pb3d_ctx* ctx);
 
 // grid size for grid-stride streaming kernels: enough blocks to fill 256 CUs, capped
 // blocks_per_cu <= 0: no cap -- one workgroup per tile of the stream.  For write-heavy or latency-heavy streams the dispatcher balances
@@ -170,6 +176,12 @@ __device__ __forceinline__ u32 pb3d_div(u32 n, const pb3d_magic g) {
     const u32 t = __umulhi(g.m, n);
     return (t + ((n - t) >> g.sa)) >> g.sb;
 }
+
+// what a labelling leaves on the device (csrc/ccl.hip): total[k] = components of colour k, records[(k * dcap + c) * 64] = 64-byte statistics
+// record of component c + 1 {int lo[3], hi[3] (inclusive), pad[2]; u64 count, sum[3]}, valid for c < min(total[k], dcap)
+struct pb3d_ccl_dev { const i64* total; const char* records; int dcap; };
+int pb3d_ccl_label_on_device(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64_t A1, int64_t A2, const uint8_t color[3], int channels, int32_t* d_labels,
+                             int64_t cap, pb3d_ccl_dev* dev);
 
 // ---- kernels' host launchers used across translation units ---------------------------------
 // process_voxel_grid through the bit-sliced chain (csrc/sliced.hip); *took = 0: not applicable, nothing written

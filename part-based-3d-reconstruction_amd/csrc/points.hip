@@ -612,7 +612,7 @@ int pb3d_points_count_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int6
         PB3D_CHECK_LAUNCH();
     }
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     *n = *(i64*)ctx->pinned;
     return PB3D_OK;
 }
@@ -668,7 +668,7 @@ int pb3d_points_extract_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, in
     else hipLaunchKernelGGL((k_points_fill16<3, true>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)nullptr, d_pts, d_cols, st, (const unsigned short*)nullptr);
     PB3D_CHECK_LAUNCH();
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, st.total, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     *n = *(i64*)ctx->pinned;
     if (*n < 0) {          // the look-back was abandoned (a dispatch order this code does not expect): nothing hung, nothing was written
         *n = 0;

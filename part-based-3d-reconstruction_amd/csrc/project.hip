@@ -500,7 +500,7 @@ int pb3d_partwise_iou_dev(pb3d_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b,
                        (unsigned long long*)counts);
     PB3D_CHECK_LAUNCH();
     PB3D_HIP(hipMemcpyAsync(ctx->pinned, counts, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    PB3D_HIP(hipStreamSynchronize(ctx->stream));
+    PB3D_TRY(pb3d_stream_sync(ctx));
     const unsigned long long* h = (const unsigned long long*)ctx->pinned;
     for (int k = 0; k < ncolors; ++k) { inter[k] = (int64_t)h[2 * k]; uni[k] = (int64_t)h[2 * k + 1]; }
     return PB3D_OK;
@@ -577,7 +577,7 @@ int pb3d_project_iou_batch_dev(pb3d_ctx* ctx, const void* d_pts, int pts_f64, co
                            ncolors, (const u8*)dcolors, (unsigned long long*)counts);
         hipok(hipGetLastError(), "k_iou_winners_batch");
         hipok(hipMemcpyAsync(hc, counts, (size_t)kn * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
-        hipok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        ++ctx->sync_count; hipok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
         if (rc != PB3D_OK) break;
         for (i64 k = 0; k < kn; ++k)
             for (int c = 0; c < ncolors; ++c) {

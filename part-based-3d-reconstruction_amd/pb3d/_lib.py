@@ -35,6 +35,8 @@ _SIGNATURES = {
     "pb3d_dev_memset": [vp, vp, C.c_int, C.c_size_t],
     "pb3d_h2d": [vp, vp, vp, C.c_size_t],
     "pb3d_d2h": [vp, vp, vp, C.c_size_t],
+    "pb3d_h2d_async": [vp, vp, vp, C.c_size_t],
+    "pb3d_sync_count": [vp],
     "pb3d_d2d": [vp, vp, vp, C.c_size_t],
     "pb3d_event_create": [vp, C.POINTER(vp)],
     "pb3d_event_record": [vp, vp],
@@ -84,9 +86,13 @@ _SIGNATURES = {
     "pb3d_label_colors_stats_dev": [vp, vp, i64, i64, i64, u8p, C.c_int, vp, i64p, i64, C.c_int, i64p, i64p, i64p, intp],
     "pb3d_label_values_stats_dev": [vp, vp, i64, i64, i64, u8p, C.c_int, vp, i64p, i64, C.c_int, i64p, i64p, i64p, intp],
     "pb3d_guided_carve_color_dev": [vp, vp, vp, C.c_int, C.c_int, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, i64p, intp],
+    "pb3d_guided_carve_queue_dev": [vp, vp, vp, C.c_int, C.c_int, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, vp, intp],
+    "pb3d_recolor_backward_dev": [vp, vp, i64, i64, i64, u8p, u8p, C.c_int, C.c_int, C.c_int, vp, vp],
     "pb3d_component_stats_dev": [vp, vp, i64, i64, i64, i64, i64p, i64p, i64p],
     "pb3d_crop_occupancy_dev": [vp, vp, i64, i64, i64, i64p, i64p, vp],
+    "pb3d_crop_occupancy_label_dev": [vp, vp, i64, i64, i64, i64p, i64p, vp],
     "pb3d_component_paste_dev": [vp, vp, vp, C.c_int32, vp, i64, i64, i64, i64p, i64p, vp],
+    "pb3d_component_paste_label_dev": [vp, vp, vp, C.c_int32, vp, i64, i64, i64, i64p, i64p, vp],
     "pb3d_guided_carve_dev": [vp, vp, vp, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, i64p, intp],
     "pb3d_guided_carve_label_dev": [vp, vp, vp, i64, i64, i64, i64, i64p, u8p, i64p, i64, C.c_int, i64p, intp],
     "pb3d_label_value_stats_dev": [vp, vp, i64, i64, i64, C.c_uint8, vp, i64p, i64, C.c_int, i64p, i64p, i64p, intp],
@@ -118,7 +124,7 @@ _SIGNATURES = {
     "pb3d_project_resolve_keys_dev": [vp, vp, C.c_int, C.c_int, vp],
     "pb3d_allreduce_max_u64_dev": [vp, vp, C.c_size_t],
 }
-_RESTYPES = {"pb3d_dtype_bytes": C.c_size_t, "pb3d_last_error": C.c_char_p, "pb3d_destroy": None, "pb3d_event_destroy": None}
+_RESTYPES = {"pb3d_dtype_bytes": C.c_size_t, "pb3d_sync_count": C.c_int64, "pb3d_last_error": C.c_char_p, "pb3d_destroy": None, "pb3d_event_destroy": None}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

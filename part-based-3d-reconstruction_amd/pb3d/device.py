@@ -32,6 +32,14 @@ class DeviceBuffer:
         _lib.check(_lib.load().pb3d_h2d(_lib.ctx(), self.at(byte_offset), a.ctypes.data_as(C.c_void_p), a.nbytes))
         return self
 
+    def upload_async(self, array, byte_offset=0):
+        """upload without waiting: the bytes are staged in the context's pinned ring (pb3d_h2d_async), `array` may be reused at once"""
+        a = np.ascontiguousarray(array)
+        if byte_offset + a.nbytes > self.nbytes:
+            raise ValueError("upload exceeds the buffer")
+        _lib.check(_lib.load().pb3d_h2d_async(_lib.ctx(), self.at(byte_offset), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return self
+
     def download(self, shape, dtype=np.uint8, byte_offset=0):
         out = _hostmem.empty(shape, dtype)
         if byte_offset + out.nbytes > self.nbytes:
@@ -88,6 +96,17 @@ class DeviceGrid:
 def from_numpy(array):
     a = np.ascontiguousarray(array)
     return DeviceBuffer(a.nbytes).upload(a)
+
+
+def from_numpy_async(array):
+    """from_numpy without a host wait (small inputs: 2-D masks, descriptors)"""
+    a = np.ascontiguousarray(array)
+    return DeviceBuffer(a.nbytes).upload_async(a)
+
+
+def sync_count():
+    """how often the host has waited for the context's stream so far"""
+    return int(_lib.load().pb3d_sync_count(_lib.ctx()))
 
 
 class Event:

@@ -253,7 +253,7 @@ def partwise_carve_labels(label_grid, label_mask_exterior, label_mask_full, pale
     the last at ONE byte per voxel.  Returns (D,H,W) labels (transposed + flipped, as upstream) when the back-minaret recolouring
     runs, else (W,H,D); label_to_rgb of it is partwise_carve of the RGB grid, byte for byte (the printed log names the colours)."""
     from . import device as dev
-    from .voxel_carving_utils import _extrude_args, _extrude_dev, _lrgc_dev, _recolor_dev
+    from .voxel_carving_utils import _extrude_args, _extrude_dev, _GuidedParts, _recolor_dev, _recolor_queue
     pal = _pal(palette)
     g = _lib.as_u8(label_grid, "label_grid")
     if g.ndim != 3:
@@ -262,16 +262,22 @@ def partwise_carve_labels(label_grid, label_mask_exterior, label_mask_full, pale
     lme = _lib.as_u8(label_mask_exterior, "label_mask_exterior"); lmf = _lib.as_u8(label_mask_full, "label_mask_full")
     d_in = dev.from_numpy(g); d_a = dev.DeviceBuffer(g.size)
     live = [d_in, d_a]
+    guided = None
     try:
         _part_carve_labels_dev(d_in, (W, H, D), lme, group_jobs, pal, d_a)
+        # all part labels in ONE labelling, their component loops queued behind it (voxel_carving_utils._GuidedParts)
+        d_lab = dev.DeviceBuffer(W * H * D * 4)
+        live.append(d_lab)
+        parts = []
         for part, angle in part_symmetry.items():
             lab = pal.label_of(part)
-            mask2d = lme == lab
-            colour = pal.colors[lab - 1]
-            if not np.any(mask2d):
-                print(f"[SKIP] No mask for color {colour}")
-                continue
-            _lrgc_dev(d_a, (W, H, D), mask2d, colour, angle, label=lab)
+            parts.append((pal.colors[lab - 1], lme == lab, angle, int(lab)))
+        guided = _GuidedParts(d_a, (W, H, D), parts, d_lab, channels=1)
+        d_b = guided.run()
+        if d_b is not d_a:
+            live.append(d_b)
+            d_a.free(); live.remove(d_a)
+            d_a = d_b
         for part, depth in extrusion_depths.items():
             if int(depth) <= 0:
                 continue
@@ -279,7 +285,7 @@ def partwise_carve_labels(label_grid, label_mask_exterior, label_mask_full, pale
             mask = lmf == lab
             for axis in (2, 0):
                 vt, vw = _extrude_args((W, H, D), mask, axis, "+")
-                d_v = dev.from_numpy(vt)
+                d_v = dev.from_numpy_async(vt)
                 try:
                     for direction in ("+", "-"):
                         _extrude_dev(d_a, d_a, (W, H, D), vt, vw, axis, direction, depth, lab, d_valid=d_v, label=True)
@@ -287,10 +293,17 @@ def partwise_carve_labels(label_grid, label_mask_exterior, label_mask_full, pale
                     d_v.free()
         if recolor_back_minarets:
             _lib.check(_lib.load().pb3d_orient_label_dev(_lib.ctx(), C.c_void_p(d_a.ptr), W, H, D, C.c_void_p(d_in.ptr)))
-            _recolor_dev(d_in, (D, H, W), pal.label_of("front_minarets"), pal.label_of("back_minarets"), 2, 0, label=True)
+            fm, bm = pal.label_of("front_minarets"), pal.label_of("back_minarets")
+            queued = _recolor_queue(d_in, (D, H, W), fm, bm, 2, 0, d_lab, guided.status_ptr(), label=True)
+            status = guided.finish(with_status=queued)
+            if queued and status[1]:
+                _recolor_dev(d_in, (D, H, W), fm, bm, 2, 0, label=True)
             return d_in.download((D, H, W))
+        guided.finish()
         return d_a.download(g.shape)
     finally:
+        if guided is not None:
+            guided.free()
         for b in live:
             b.free()
 

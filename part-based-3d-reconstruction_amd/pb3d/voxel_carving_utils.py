@@ -403,14 +403,16 @@ def _check_angle_step(angle):
         raise ValueError("range() arg 3 must not be zero")
 
 
-def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
+def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None, d_lab=None):
     """left_right_guided_carve on a device-resident grid.  Returns the DeviceBuffer that holds the result: d_col itself when the
     fused component loop ran (csrc/guided.hip: in place, one launch pair per batch of components), else a new buffer."""
     from . import device as dev
     W, H, D = shape3
     lib, ctx = _lib.load(), _lib.ctx()
     nbytes = W * H * D * (3 if label is None else 1)      # label: d_col is a 1-byte label volume and `label` the part's label value
-    d_lab = dev.DeviceBuffer(W * H * D * 4)
+    own_lab = d_lab is None
+    if own_lab:
+        d_lab = dev.DeviceBuffer(W * H * D * 4)
     d_carved = None
     tmp = []
     try:
@@ -441,12 +443,15 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
                                                  cn.ctypes.data_as(_lib.i64p), C.byref(took)))
             if took.value:
                 counts = cn
-        if counts is None and label is not None:
-            raise ValueError("left_right_guided_carve on labels: a component's 32-plane slice does not fit the LDS (or angle < 0); use the RGB form")
         if counts is None:
             # a crop too large for the LDS-resident chain (or an empty angle loop): component by component, into a copy -- these entries
             # read labels at every voxel of a crop, so the volume is labelled again, in full
-            _label(d_col, (W, H, D), cu8, d_lab)
+            if label is None:
+                _label(d_col, (W, H, D), cu8, d_lab)
+            else:
+                _label_stats(d_col, (W, H, D), cu8, d_lab, cap=1024, members_only=False)
+            crop_fn = lib.pb3d_crop_occupancy_dev if label is None else lib.pb3d_crop_occupancy_label_dev
+            paste_fn = lib.pb3d_component_paste_dev if label is None else lib.pb3d_component_paste_label_dev
             d_carved = dev.DeviceBuffer(nbytes)
             _lib.check(lib.pb3d_d2d(ctx, C.c_void_p(d_carved.ptr), C.c_void_p(d_col.ptr), nbytes))
             vmax = int(max((b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]) for b in bbox))
@@ -458,15 +463,14 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
                 x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
                 Wc, Hc, Dc = x1 - x0, y1 - y0, z1 - z0
                 lo = (C.c_int64 * 3)(x0, y0, z0); hi = (C.c_int64 * 3)(x1, y1, z1)
-                _lib.check(lib.pb3d_crop_occupancy_dev(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
+                _lib.check(crop_fn(ctx, C.c_void_p(d_col.ptr), W, H, D, lo, hi, C.c_void_p(d_occ.ptr)))
                 if angle < 0:
                     src = d_occ     # empty angle loop: the crop's occupancy is returned as is
                 else:
                     dev.process_grid(d_occ, Wc, Hc, Dc, d_m.at(offs[i - 1]), int(min(angle, 91)), d_out, d_tmp)
                     src = d_out
                 _lib.check(lib.pb3d_count_nonzero_dev(ctx, C.c_void_p(src.ptr), Wc * Hc * Dc, d_cnt.at(8 * (i - 1))))
-                _lib.check(lib.pb3d_component_paste_dev(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D,
-                                                        lo, hi, C.c_void_p(d_carved.ptr)))
+                _lib.check(paste_fn(ctx, C.c_void_p(d_col.ptr), C.c_void_p(d_lab.ptr), i, C.c_void_p(src.ptr), W, H, D, lo, hi, C.c_void_p(d_carved.ptr)))
             counts = d_cnt.download((num,), np.int64)
         lines = []
         for i in range(1, num + 1):
@@ -480,9 +484,154 @@ def _lrgc_dev(d_col, shape3, mask2d, target_color, angle, label=None):
     finally:
         if d_carved is not None:
             d_carved.free()
-        d_lab.free()
+        if own_lab:
+            d_lab.free()
         for b in tmp:
             b.free()
+
+
+def _pack_crop_masks(mask2d, bbox):
+    """every component's 2-D crop mask (reference :189) in one byte string: (packed, offsets)"""
+    masks, offs, o = [], [], 0
+    for b in bbox:
+        x0, y0, z0, x1, y1, z1 = (int(v) for v in b)
+        m = _lib.truth_u8(_mask_to_wh(mask2d[y0:y1, x0:x1], x1 - x0, y1 - y0))
+        masks.append(np.ascontiguousarray(m).reshape(-1)); offs.append(o); o += (m.size + 15) & ~15
+    packed = np.zeros(max(o, 16), np.uint8)
+    for m, off in zip(masks, offs):
+        packed[off:off + m.size] = m
+    return packed, np.asarray(offs, np.int64)
+
+
+def _component_log(num, bbox, counts):
+    lines = []
+    for i in range(1, num + 1):
+        x0, y0, z0, x1, y1, z1 = (int(v) for v in bbox[i - 1])
+        lines.append(f"  - Component {i}: bbox ({x0},{y0},{z0}) → ({x1},{y1},{z1})")
+        lines.append(f"    carved voxels: {int(counts[i - 1])}")
+    return lines
+
+
+class _GuidedParts:
+    """left_right_guided_carve for SEVERAL part colours of one grid (the loop of reference :338-346) behind ONE labelling.
+
+    left_right_guided_carve(colour c) only ever clears or restores voxels of colour c (:199-201), so the membership of every OTHER
+    colour -- and with it the components, their numbering and their boxes -- is what it was before the loop started: all part colours
+    are labelled together on the grid part_carve left (pb3d_label_colors_stats_dev: the grid is read once, ONE host round trip), the
+    component loops of all parts are queued behind it in the reference's order (each crop's occupancy is taken from the grid as the
+    parts before it left it, like upstream), and the "carved voxels" counts of the printed log come back once, at the end, together
+    with the status words of whatever the caller queues behind (the recolouring).  The log text is upstream's, line for line; it is
+    emitted by finish()."""
+    CAP = 8192          # components whose counts one log buffer holds
+
+    def __init__(self, d_grid, shape3, parts, d_lab, channels=3):
+        """parts: list of (printed colour, mask2d (H,W) bool, angle, key) -- key = 3 uint8 (colour grid) or an int label value
+        (label volume), None if the colour cannot occur in a uint8 grid."""
+        from . import device as dev
+        self.dev, self.d_grid, self.shape3, self.d_lab, self.channels = dev, d_grid, shape3, d_lab, channels
+        self.items = []           # ("text", line) | ("part", printed colour, num, bbox, offset into the counts)
+        self.d_log = dev.DeviceBuffer(8 * (self.CAP + 2))
+        self.parts = list(parts)
+        self.used = 0
+
+    def status_ptr(self):
+        """two device int64 behind the counts: pb3d_recolor_backward_dev's status words come back with the log"""
+        return self.d_log.at(8 * self.CAP)
+
+    def _one_by_one(self, d_cur, part):
+        target, mask2d, angle, key = part
+        d_new = _lrgc_dev(d_cur, self.shape3, mask2d, target, angle, label=None if self.channels == 3 else key, d_lab=self.d_lab)
+        if d_new is not d_cur and d_cur is not self.d_grid:
+            d_cur.free()            # (a copy an earlier fallback made; the caller's buffer stays the caller's)
+        return d_new
+
+    def run(self):
+        """queue every part; returns the DeviceBuffer that holds the grid afterwards (d_grid unless a fallback copied it)"""
+        lib, ctx = _lib.load(), _lib.ctx()
+        W, H, D = self.shape3
+        work = [p for p in self.parts if p[1] is not None and np.any(p[1]) and p[3] is not None]
+        keys = [(int(p[3]) if isinstance(p[3], (int, np.integer)) else tuple(int(v) for v in p[3])) for p in work]
+        one_by_one = len(set(keys)) != len(keys)          # a colour named twice: its second carve sees what the first one left
+        groups = [work[i:i + 8] for i in range(0, len(work), 8)]
+        where = {}                  # id(part) -> (colour index in its labelling, (n, bbox, count, sums) or None)
+        d_cur = self.d_grid
+        for part in self.parts:
+            target, mask2d, angle, key = part
+            if mask2d is None or not np.any(mask2d):
+                self.items.append(("text", f"[SKIP] No mask for color {target}"))
+                continue
+            if one_by_one:
+                self.flush()
+                d_cur = self._one_by_one(d_cur, part)
+                continue
+            if key is None:
+                self.items.append(("text", f"[{target}] 3D components: 0"))
+                continue
+            if id(part) not in where:        # the next group of (at most eight) colours: one labelling for all of them
+                grp = next(g for g in groups if any(q is part for q in g))
+                res = _label_stats_multi(d_cur, (W, H, D), [q[3] for q in grp], self.d_lab, cap=1024, members_only=True)
+                for k, q in enumerate(grp):
+                    where[id(q)] = (k, res[k])
+            k, r = where[id(part)]
+            queued = False
+            if r is not None and r[0] == 0:
+                self.items.append(("text", f"[{target}] 3D components: 0"))
+                queued = True
+            elif r is not None:
+                num, bbox = r[0], r[1]
+                if isinstance(angle, (bool, np.bool_)) or not isinstance(angle, (int, np.integer)) or angle == 0:
+                    self.items.append(("text", f"[{target}] 3D components: {num}"))
+                    self.flush()
+                    _check_angle_step(angle)        # raises what upstream's range() raises
+                if angle > 0 and self.used + num <= self.CAP:
+                    packed, offs = _pack_crop_masks(mask2d, bbox)
+                    bb = np.ascontiguousarray(bbox, np.int64)
+                    took = C.c_int(0)
+                    _lib.check(lib.pb3d_guided_carve_queue_dev(ctx, C.c_void_p(d_cur.ptr), C.c_void_p(self.d_lab.ptr), k, self.channels, W, H, D, num,
+                                                               bb.ctypes.data_as(_lib.i64p), _lib.p_u8(packed), offs.ctypes.data_as(_lib.i64p), packed.size,
+                                                               int(min(angle, 91)), self.d_log.at(8 * self.used), C.byref(took)))
+                    if took.value:
+                        self.items.append(("part", target, num, bbox, self.used))
+                        self.used += num
+                        queued = True
+            if not queued:
+                # more components than the statistics hold, an empty angle loop, or a crop too large for the LDS-resident chain: this part and
+                # the ones after it go one by one (their labellings would overwrite the shared one)
+                self.flush()
+                one_by_one = True
+                d_cur = self._one_by_one(d_cur, part)
+        return d_cur
+
+    def _emit(self, log):
+        lines = []
+        for it in self.items:
+            if it[0] == "text":
+                lines.append(it[1])
+            else:
+                _, target, num, bbox, off = it
+                lines.append(f"[{target}] 3D components: {num}")
+                lines += _component_log(num, bbox, log[off:off + num])
+        if lines:
+            print("\n".join(lines))
+        self.items = []
+
+    def flush(self):
+        """emit the log collected so far (waits for the device when a queued part's counts are still there)"""
+        log = self.d_log.download((self.used,), np.int64) if any(it[0] == "part" for it in self.items) else None
+        self._emit(log)
+
+    def finish(self, with_status=False):
+        """ONE download: the counts of every queued part (+ the two status words behind them); emits the log; returns the status"""
+        if not with_status:
+            self.flush()
+            return None
+        log = self.d_log.download((self.CAP + 2,), np.int64)
+        self._emit(log)
+        return log[self.CAP:]
+
+    def free(self):
+        if self.d_log is not None:
+            self.d_log.free(); self.d_log = None
 
 
 def left_right_guided_carve(colored_grid, semantic_mask, target_color, angle=60, visualize=False, stride=2):
@@ -601,19 +750,37 @@ def recolor_backward_components(voxel_grid, color, new_color, k=4, sort_axis=2):
     if g.size == 0:
         return g.copy()
     d_g = dev.from_numpy(g)
+    d_lab = dev.DeviceBuffer(g.size // 3 * 4); d_st = dev.DeviceBuffer(16)
     try:
-        _recolor_dev(d_g, g.shape[:3], color, new_color, k, sort_axis)
+        # labelling, keep decision and painting on the device (pb3d_recolor_backward_dev); the host decides for scenes with more
+        # components than that entry takes
+        if _recolor_queue(d_g, g.shape[:3], color, new_color, k, sort_axis, d_lab, C.c_void_p(d_st.ptr)) and d_st.download((2,), np.int64)[1]:
+            _recolor_dev(d_g, g.shape[:3], color, new_color, k, sort_axis)
         return d_g.download(g.shape)
     finally:
-        d_g.free()
+        d_g.free(); d_lab.free(); d_st.free()
+
+
+def _recolor_queue(d_g, shape3, color, new_color, k, sort_axis, d_lab, d_status, label=False):
+    """recolor_backward_components queued on the device without a host wait (pb3d_recolor_backward_dev); False if nothing was queued"""
+    A0, A1, A2 = shape3
+    cu8 = int(color) if label else _color_u8(color)
+    if cu8 is None or A0 * A1 * A2 == 0:
+        return False
+    c3 = np.array([cu8, 0, 0], np.uint8) if label else cu8
+    nc = np.array([int(new_color), 0, 0], np.uint8) if label else np.ascontiguousarray(np.asarray(new_color).astype(np.uint8).reshape(3))
+    _lib.check(_lib.load().pb3d_recolor_backward_dev(_lib.ctx(), C.c_void_p(d_g.ptr), A0, A1, A2, _lib.p_u8(c3), _lib.p_u8(nc), int(k), int(sort_axis),
+                                                     1 if label else 3, C.c_void_p(d_lab.ptr), d_status))
+    return True
 
 
 def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_full, part_colors_np, group_jobs, part_symmetry,
                    extrusion_depths, recolor_back_minarets=True, visualize=False, stride=4):
     """Part-wise refinement after global carving; reference :302-400.  Returns (D,H,W,3) when the
     back-minaret recolouring runs (transposed + flipped, as upstream), else (W,H,D,3).
-    The grid stays resident in HBM from the first stage to the last (one upload, one download); only with
-    visualize=True are intermediate grids brought back for plotting."""
+    The grid stays resident in HBM from the first stage to the last (one upload, one download) and the host waits for the device
+    TWICE: for the component boxes of all part colours (one labelling) and for the finished grid -- the printed log (upstream's text,
+    line for line) is emitted at the end.  Only with visualize=True are intermediate grids brought back for plotting."""
     from . import device as dev
     resident = isinstance(colored_voxel_grid, dev.DeviceGrid)     # then the result is a DeviceGrid too (the input stays the caller's)
     g = colored_voxel_grid if resident else _lib.as_u8(colored_voxel_grid, "colored_voxel_grid")
@@ -639,30 +806,31 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
     d_in = dev.DeviceBuffer(nb) if resident else dev.from_numpy(g)       # scratch later on; a resident input is only read
     d_a = dev.DeviceBuffer(nb)
     live = [d_in, d_a]
+    guided = None
     try:
-        d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve)
+        d_ms = dev.from_numpy_async(msub); d_mc = dev.from_numpy_async(mcarve)
         live += [d_ms, d_mc]
         _lib.check(lib.pb3d_part_carve_dev(ctx, C.c_void_p(g.buf.ptr if resident else d_in.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr), angles, skip,
                                            len(group_jobs), C.c_void_p(d_a.ptr)))
-        dev.sync()
         show(d_a, tuple(g.shape), "After part-wise symmetric carving (global symmetry on each part)")
-        # 2. component-guided symmetry
+        # 2. component-guided symmetry: ONE labelling for all part colours, the component loops queued behind it
         sm_ext = np.asarray(semantic_mask_exterior)
         key_ext = _color_key(sm_ext)
+        d_lab = dev.DeviceBuffer(W * H * D * 4)
+        live.append(d_lab)
+        parts = []
         for part, angle in part_symmetry.items():
             target = part_colors_np[part]
-            mask2d = _is_color(sm_ext, key_ext, target)
-            if not np.any(mask2d):
-                print(f"[SKIP] No mask for color {target}")
-                continue
-            d_b = _lrgc_dev(d_a, (W, H, D), mask2d, target, angle)
-            if d_b is not d_a:          # (the fused component loop works in place)
-                live.append(d_b)
-                d_a.free(); live.remove(d_a)
-                d_a = d_b
+            parts.append((target, _is_color(sm_ext, key_ext, target), angle, _color_u8(target)))
+        guided = _GuidedParts(d_a, (W, H, D), parts, d_lab)
+        d_b = guided.run()
+        if d_b is not d_a:          # (a part that went component by component works on a copy)
+            live.append(d_b)
+            d_a.free(); live.remove(d_a)
+            d_a = d_b
         show(d_a, g.shape, "After part-wise symmetric carving (local symmetry on each part)")
         # 3. interior extrusion: four directions per part, IN PLACE (a column is scanned and painted by one wavefront / thread), the
-        #    part's mask uploaded once per axis orientation
+        #    part's mask uploaded once per axis orientation (staged: no host wait)
         d_b = d_in          # the input copy is no longer needed (the orientation stage below writes into it)
         sm_full = np.asarray(semantic_mask_full)
         key_full = _color_key(sm_full)
@@ -672,26 +840,33 @@ def partwise_carve(colored_voxel_grid, semantic_mask_exterior, semantic_mask_ful
             mask = _is_color(sm_full, key_full, part_colors_np[part])
             for axis in (2, 0):
                 vt, vw = _extrude_args((W, H, D), mask, axis, "+")
-                d_v = dev.from_numpy(vt)
+                d_v = dev.from_numpy_async(vt)
                 try:
                     for direction in ("+", "-"):
                         _extrude_dev(d_a, d_a, (W, H, D), vt, vw, axis, direction, depth, part_colors_np[part], d_valid=d_v)
                 finally:
                     d_v.free()
         show(d_a, g.shape, "After interior extrusion")
-        # 4. orientation + back-minaret recolouring
+        # 4. orientation + back-minaret recolouring (labelling, keep decision and painting all on the device)
         if recolor_back_minarets:
             _lib.check(lib.pb3d_orient_dev(ctx, C.c_void_p(d_a.ptr), W, H, D, C.c_void_p(d_b.ptr)))
-            _recolor_dev(d_b, (D, H, W), part_colors_np["front_minarets"], part_colors_np["back_minarets"], 2, 0)
+            queued = _recolor_queue(d_b, (D, H, W), part_colors_np["front_minarets"], part_colors_np["back_minarets"], 2, 0, d_lab, guided.status_ptr())
+            status = guided.finish(with_status=queued)          # the second (and last) wait: the log's counts + the recolouring's status
+            if queued and status[1]:
+                # more components than the device decides on: the host path (nothing was painted)
+                _recolor_dev(d_b, (D, H, W), part_colors_np["front_minarets"], part_colors_np["back_minarets"], 2, 0)
             show(d_b, (D, H, W, 3), "After back-minaret recoloring")
             if resident:
                 live.remove(d_b)
                 return dev.DeviceGrid(d_b, (D, H, W, 3))
             return d_b.download((D, H, W, 3))
+        guided.finish()
         if resident:
             live.remove(d_a)
             return dev.DeviceGrid(d_a, tuple(g.shape))
         return d_a.download(g.shape)
     finally:
+        if guided is not None:
+            guided.free()
         for b in live:
             b.free()

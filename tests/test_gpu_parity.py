@@ -1499,6 +1499,100 @@ def test_label_chain_end_to_end(pb3d_gpu, golden, name):
         assert np.array_equal(p1, p2) and np.array_equal(c1, c2) and tuple(s1) == tuple(s2), st
 
 
+def test_partwise_carve_host_waits_and_fallbacks(pb3d_gpu, golden, oracle):
+    """partwise_carve (reference :302-400) queues every stage behind ONE labelling of all part colours: the resident chain waits for the
+    device at most twice (pb3d_sync_count), the printed log and the grid are the oracle's.  The paths off the main road give the same
+    result and log: a part colour named twice (second carve sees what the first left), a crop too large for the LDS-resident component
+    loop (x-z box beyond 138 x 138: per-component entries, RGB and label form -- ADVICE r3), an empty angle loop (angle > 90)."""
+    import contextlib
+    import io
+    from pb3d import device as dev
+    PC = pb3d_gpu.PART_COLORS; PCN = pb3d_gpu.PART_COLORS_NP
+    g = golden("f5_Taj_96")
+    gc = pb3d_gpu.global_carve(g["binary"], g["ext"], 90)
+    b1, b2 = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(b2):
+        want = oracle.partwise_carve(gc, g["ext"], g["sem"], PCN, JOBS_NB1, PART_SYMMETRY, EXTRUSION)
+    d_gc = dev.DeviceGrid(dev.from_numpy(gc), gc.shape)
+    with contextlib.redirect_stdout(io.StringIO()):
+        pb3d_gpu.partwise_carve(d_gc, g["ext"], g["sem"], PCN, JOBS_NB1, PART_SYMMETRY, EXTRUSION).free()        # (scratch buffers of this shape exist now)
+    w0 = dev.sync_count()
+    with contextlib.redirect_stdout(b1):
+        d_res = pb3d_gpu.partwise_carve(d_gc, g["ext"], g["sem"], PCN, JOBS_NB1, PART_SYMMETRY, EXTRUSION)
+    waits = dev.sync_count() - w0
+    got = d_res.numpy(); d_res.free(); d_gc.free()
+    assert np.array_equal(got, want) and b1.getvalue() == b2.getvalue()
+    assert waits <= 2, waits
+    # a colour named twice + an empty angle loop: one by one, same log
+    PCN2 = dict(PCN); PCN2["dome_again"] = PCN["dome"]
+    sym2 = {"dome": 45, "chhatris": 120, "dome_again": 30, "front_minarets": 5}
+    b1, b2 = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(b1):
+        got = pb3d_gpu.partwise_carve(gc, g["ext"], g["sem"], PCN2, JOBS_NB1, sym2, EXTRUSION)
+    with contextlib.redirect_stdout(b2):
+        want = oracle.partwise_carve(gc, g["ext"], g["sem"], PCN2, JOBS_NB1, sym2, EXTRUSION)
+    assert np.array_equal(got, want) and b1.getvalue() == b2.getvalue()
+    sym3 = {"dome": 45, "chhatris": 120, "front_minarets": 5}
+    b1, b2 = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(b1):
+        got = pb3d_gpu.partwise_carve(gc, g["ext"], g["sem"], PCN, JOBS_NB1, sym3, EXTRUSION, recolor_back_minarets=False)
+    with contextlib.redirect_stdout(b2):
+        want = oracle.partwise_carve(gc, g["ext"], g["sem"], PCN, JOBS_NB1, sym3, EXTRUSION, recolor_back_minarets=False)
+    assert np.array_equal(got, want) and b1.getvalue() == b2.getvalue()
+    # a crop whose 32-plane slice does not fit the LDS: a 150 x 150 slab of one colour (+ a small second part that still takes the fused loop
+    # in the calls after it), RGB form and label form
+    rng = np.random.default_rng(5)
+    W, H, D = 160, 12, 160
+    grid = np.zeros((W, H, D, 3), np.uint8)
+    grid[4:154, 2:9, 5:155] = PCN["plinth"]; grid[60:80, 9:12, 60:90] = PCN["dome"]; grid[2:4, 0:2, 0:3] = PCN["chhatris"]
+    grid[rng.random((W, H, D)) < 0.02] = 0
+    ext = np.zeros((H, W, 3), np.uint8); ext[:] = PC["background"]
+    ext[2:9, 4:154] = PC["plinth"]; ext[9:12, 55:85] = PC["dome"]; ext[0:2, 0:6] = PC["chhatris"]
+    ext[rng.random((H, W)) < 0.05] = PC["background"]
+    sym4 = {"chhatris": 45, "plinth": 30, "dome": 45}
+    jobs4 = [(["plinth"], 90), (["dome"], 90), (["chhatris"], 90)]
+    b1, b2 = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(b1):
+        got = pb3d_gpu.partwise_carve(grid, ext, ext, PCN, jobs4, sym4, {}, recolor_back_minarets=False)
+    with contextlib.redirect_stdout(b2):
+        want = oracle.partwise_carve(grid, ext, ext, PCN, jobs4, sym4, {}, recolor_back_minarets=False)
+    assert b1.getvalue() == b2.getvalue() and "bbox (5,2,7) → (154,9,155)" in b1.getvalue()
+    assert np.array_equal(got, want), int((got != want).any(-1).sum())
+    pal = pb3d_gpu.Palette.from_part_colors(PC)
+    for part, angle in (("plinth", 30), ("dome", 45)):
+        b1, b2 = io.StringIO(), io.StringIO()
+        with contextlib.redirect_stdout(b1):
+            got = pb3d_gpu.left_right_guided_carve(grid, ext, PCN[part], angle=angle)
+        with contextlib.redirect_stdout(b2):
+            want = oracle.left_right_guided_carve(grid, ext, PCN[part], angle=angle)
+        assert np.array_equal(got, want) and b1.getvalue() == b2.getvalue(), part
+        b3 = io.StringIO()
+        with contextlib.redirect_stdout(b3):
+            gl = pb3d_gpu.left_right_guided_carve_labels(pb3d_gpu.rgb_to_label(grid, pal), pal.mask_to_labels(ext), pal.label_of(part), angle=angle, log_color=PCN[part])
+        assert np.array_equal(pb3d_gpu.label_to_rgb(gl, pal), want) and b3.getvalue() == b2.getvalue(), part
+
+
+def test_recolor_backward_many_components(pb3d_gpu, oracle):
+    """recolor_backward_components (reference :252-266) on scenes with more components than the labelling's statistics block holds
+    (1024: the separate statistics pass regrows other scratch buffers -- ADVICE r3 medium) and more than the device-side keep decision
+    takes (2048: host path), on a fresh order of calls; plus equal means (stable order of sorted())."""
+    rng = np.random.default_rng(9)
+    col = np.array(pb3d_gpu.PART_COLORS["front_minarets"], np.uint8); new = np.array(pb3d_gpu.PART_COLORS["back_minarets"], np.uint8)
+    for shp, dens, k, axis in [((40, 36, 44), 0.08, 3, 0), ((64, 60, 50), 0.10, 700, 2), ((30, 20, 26), 0.5, 2, 1), ((8, 6, 40), 0.3, 4, 2)]:
+        grid = np.zeros(shp + (3,), np.uint8)
+        grid[rng.random(shp) < dens] = col
+        grid[rng.random(shp) < 0.02] = (9, 9, 9)
+        want = oracle.recolor_backward_components(grid, col, new, k=k, sort_axis=axis)
+        got = pb3d_gpu.recolor_backward_components(grid, col, new, k=k, sort_axis=axis)
+        assert np.array_equal(got, want), (shp, dens, k, axis)
+    # equal means: mirrored blobs on the sort axis
+    grid = np.zeros((20, 10, 20, 3), np.uint8)
+    for z in (2, 8, 14):
+        grid[5:8, 2:5, z:z + 3] = col
+    want = oracle.recolor_backward_components(grid, col, new, k=2, sort_axis=0)
+    assert np.array_equal(pb3d_gpu.recolor_backward_components(grid, col, new, k=2, sort_axis=0), want)
+
+
 def test_rot90_wide_tile_kernel(pb3d_gpu, oracle):
     """the 256 x 256-tile form of the 90-degree step (grids from 256 x 256 planes up; tune rot90_wide = 2 pins the 128-tile kernel):
     both bit-exact on whole and clipped tiles."""

@@ -50,6 +50,19 @@ for rep in range(3):
     for d in (d_gc, d_pc, d_full):
         d.free()
 res["resident_chain"] = {"global+part+partwise_s": round(t1 - t0, 4), "final_download_s": round(t2 - t1, 4), "equals_host_chain": same}
+# partwise_carve alone on a resident grid: wall time per call and the number of times the host waits for the device inside it
+from pb3d import device as dev  # noqa: E402
+d_gc = pb3d.global_carve(g["binary"], g["ext"], angle_interval=90, on_device=True)
+walls, waits = [], []
+for rep in range(12):
+    dev.sync(); w0 = dev.sync_count(); t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        d_full = pb3d.partwise_carve(d_gc, g["ext"], g["sem"], PCN, group_jobs, part_symmetry, extrusion_depths)
+    w1 = dev.sync_count(); dev.sync(); walls.append(time.perf_counter() - t0); waits.append(w1 - w0)
+    d_full.free()
+d_gc.free()
+walls = sorted(walls[2:])
+res["resident_partwise_carve"] = {"wall_ms_median": round(walls[len(walls) // 2] * 1e3, 3), "wall_ms_min": round(walls[0] * 1e3, 3), "host_waits_per_call": waits[-1]}
 oriented = np.flip(pc.transpose(2, 1, 0, 3), axis=1)
 eq = lambda grid, name: np.all(grid == np.array(pb3d.PART_COLORS[name], np.uint8), axis=-1)
 res["results1_pinned_parts_exact"] = bool(all(np.array_equal(eq(oriented, p), eq(stored, p)) for p in ("plinth", "chhatris")))
