@@ -91,59 +91,57 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
     const int R = 1 << lgR;
     const int lr = lane & ((64 >> lgR) - 1);                   // this lane's 16 voxels: 16 lr .. of row rw0 + lane / (64 / R)
     const int tw = lane & ((16 >> lgR) - 1);                   // lanes 0..15: window tw of row rw0 + lane / (16 / R)
-    for (i64 rw0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; rw0 < rows; rw0 += (i64)gridDim.x * 4 * R) {
-        const i64 vrow = rw0 + (lane >> (6 - lgR));
-        const i64 wrow = rw0 + ((lane & 15) >> (4 - lgR));
-        const u32 base = (u32)vrow * (u32)A2;
-        u32 carry_prev[KT];
-        int carry_hi[KT];
+    constexpr int NW = C == 1 ? 4 : 12;                        // dwords a lane loads per task
+    // A task = 1024 voxels: R whole rows, or one chunk of a row longer than that (its chunks in order: run carries).  One task per wave
+    // and as many workgroups as there are tasks: a persistent grid that requests the NEXT task's voxels before comparing this one's was
+    // measured SLOWER (692 against 615 us at 1024^3, 54 against 48 us for four colours at Taj 512) -- as for the headline carve kernel,
+    // the dispatcher's many small workgroups hide the latency better than a software pipeline does.
+    auto load_task = [&](i64 rw0, int c0, u32* w) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) { carry_prev[k] = 0; carry_hi[k] = 0; }
-        for (int c0 = 0; c0 < A2; c0 += kChunkVox) {             // (several chunks only when R == 1)
+        for (int k = 0; k < NW; ++k) w[k] = 0u;
+        const i64 vrow = rw0 + (lane >> (6 - lgR));
+        const int v = c0 + 16 * lr;
+        if (vrow >= rows || v >= A2) return;
+        const i64 boff = C * (vrow * (i64)A2 + v);
+        if (boff + 4 * NW <= nbytes) {                               // (past the row's end these are the next row's voxels: masked off below)
+            const u32x4a1* p = (const u32x4a1*)(grid + boff);
+#pragma unroll
+            for (int k = 0; k < NW / 4; ++k) { const u32x4a1 t = p[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
+        } else {                                                     // the grid's last bytes: byte by byte
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                u32 t = 0;
+                for (int b = 0; b < 4; ++b) { const i64 o = boff + 4 * k + b; if (o < nbytes) t |= (u32)grid[o] << (8 * b); }
+                w[k] = t;
+            }
+        }
+    };
+    u32 wcur[NW + 1];
+    wcur[NW] = 0u;
+    u32 carry_prev[KT], carry_node[KT];
+    for (i64 rw0 = ((i64)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; rw0 < rows; rw0 += (i64)gridDim.x * 4 * R) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { carry_prev[k] = 0; carry_node[k] = 0; }
+        for (int c0 = 0; c0 < A2; c0 += kChunkVox) {
+            load_task(rw0, c0, wcur);
+        {
+            const i64 vrow = rw0 + (lane >> (6 - lgR));
+            const i64 wrow = rw0 + ((lane & 15) >> (4 - lgR));
             // ---- the 16 voxels of this lane as 24-bit (8-bit) values
             const int v = c0 + 16 * lr;
             const bool have = vrow < rows && v < A2;
             u32 vox[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vox[i] = 0xffffffffu;              // (no colour: never equal)
             u32 nz = 0;
-            if (C == 1 && have) {
-                const i64 boff = (i64)base + v;
-                u32 w[4];
-                if (boff + 16 <= nbytes) { const u32x4a1 t = *(const u32x4a1*)(grid + boff); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
-                else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        u32 t = 0;
-                        for (int b = 0; b < 4; ++b) { const i64 o = boff + 4 * k + b; if (o < nbytes) t |= (u32)grid[o] << (8 * b); }
-                        w[k] = t;
-                    }
-                }
-                nz = w[0] | w[1] | w[2] | w[3];
+            for (int k = 0; k < NW; ++k) nz |= wcur[k];
+            if (C == 1) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) vox[i] = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
-            } else if (have) {
-                const i64 boff = 3 * ((i64)base + v);
-                u32 w[13];
-                w[12] = 0u;
-                if (boff + 48 <= nbytes) {                               // (past the row's end these are the next row's voxels: masked off below)
-                    const u32x4a1* p = (const u32x4a1*)(grid + boff);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { const u32x4a1 t = p[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
-                } else {                                                 // the grid's last 47 bytes: byte by byte
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        u32 t = 0;
-                        for (int b = 0; b < 4; ++b) { const i64 o = boff + 4 * k + b; if (o < nbytes) t |= (u32)grid[o] << (8 * b); }
-                        w[k] = t;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 12; ++k) nz |= w[k];
+                for (int i = 0; i < 16; ++i) vox[i] = have ? (wcur[i >> 2] >> (8 * (i & 3))) & 0xffu : 0xffffffffu;
+            } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int j = (3 * i) >> 2, sh = (3 * i) & 3;
-                    vox[i] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], (u32)sh) & 0x00ffffffu;
+                    vox[i] = have ? __builtin_amdgcn_alignbyte(wcur[j + 1], wcur[j], (u32)sh) & 0x00ffffffu : 0xffffffffu;      // (no voxel: no colour)
                 }
             }
             const u32 tail = have ? (v + 16 > A2 ? (1u << (A2 - v)) - 1u : 0xffffu) : 0u;
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
                 if (k >= K) break;
                 if (empty) {
                     if (wvalid) bits[(i64)k * nwords + wrow * P + t] = 0ull;
-                    carry_prev[k] = 0;
+                    carry_prev[k] = 0; carry_node[k] = 0;
                     continue;
                 }
                 const u32 ck = cols.c[k];
@@ -173,23 +171,32 @@ __global__ __launch_bounds__(256) void k_ccl_init(const u8* __restrict__ grid, i
                 const int hi = seg ? hi_bit(seg) : 0;                     // ... the last segment's
                 const u32 top = (u32)(w >> 63);
                 u32 prev = (u32)__shfl_up((int)top, 1);
-                int prevhi = __shfl_up(hi, 1);
-                if (tw == 0) { prev = lgR ? 0u : carry_prev[k]; prevhi = carry_hi[k]; }     // (a row's first window of this chunk)
+                if (tw == 0) prev = lgR ? 0u : carry_prev[k];             // (a row's first window of this chunk)
+                // A segment that continues the run of the window before hangs under that RUN's first segment -- not under the window
+                // before it: linked window by window, a run of 1024 voxels is a chain sixteen nodes deep, which the last pass walked one
+                // dependent load at a time.  The run's first segment sits in the nearest window below that the run does not pass
+                // through (ft: the bit-0 segment continues AND is the window's last one): one ballot + one cross-lane read.
+                const bool cont = prev && (w & 1ull);
+                const bool ft = cont && hi == 0;
+                const u32 below = (u32)__ballot(!ft) & 0xffffu & ((1u << (lane & 15)) - 1u);
+                const u32 v0 = (u32)wrow * (u32)A2 + 64u * (u32)t;
+                const u32 mynode = v0 + (u32)hi;                          // this window's last segment
+                u32 runstart = (u32)__shfl((int)mynode, below ? 31 - __clz((int)below) : 0);
+                if (!below) runstart = carry_node[k];                     // (the run came in from the chunk before: rows longer than 1024)
                 if (wvalid) {
                     bits[(i64)k * nwords + wrow * P + t] = w;
-                    const u32 v0 = (u32)wrow * (u32)A2 + 64u * (u32)t;
                     u64 sg = seg;
                     while (sg) {
                         const int i = __ffsll((unsigned long long)sg) - 1;
                         sg &= sg - 1;
-                        // a segment that continues the run of the window before hangs under that window's last segment
-                        const u32 par = (i == 0 && prev) ? v0 - 64u + (u32)prevhi : v0 + (u32)i;
+                        const u32 par = (i == 0 && cont) ? runstart : v0 + (u32)i;
                         parent[v0 + (u32)i] = ~(int)par;
                     }
                 }
+                carry_node[k] = (u32)__builtin_amdgcn_readlane((int)(ft ? runstart : mynode), 15);
                 carry_prev[k] = (u32)__builtin_amdgcn_readlane((int)top, 15);
-                carry_hi[k] = __builtin_amdgcn_readlane(hi, 15);
             }
+        }
         }
     }
 }
@@ -585,7 +592,8 @@ __global__ __launch_bounds__(256) void k_ccl_finish(const u64* __restrict__ bits
             int* dst = parent + (u32)info + (u32)p;
             if (nv >= 4) {
                 i32x4a4 o; o.x = L[0]; o.y = L[1]; o.z = L[2]; o.w = L[3];
-                *(i32x4a4*)dst = o;
+                if (SPARSE) *(i32x4a4*)dst = o;
+                else __builtin_nontemporal_store(o, (i32x4a4*)dst);       // the full label volume: 4 B/voxel streamed out once
             } else {
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
@@ -718,7 +726,7 @@ static int label_colors_impl(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, i
         int zero_is_colour = 0;
         for (int k = 0; k < K; ++k) zero_is_colour |= cols.c[k] == 0u;
         const i64 nrec = stats ? (i64)ncopies * K * dcap : 0;
-        const dim3 ig(pb3d_stream_blocks(ctx, (rows + (1 << lgR) - 1) >> lgR, 4, 0));
+        const dim3 ig(pb3d_stream_blocks(ctx, (rows + (1 << lgR) - 1) >> lgR, 4, ctx->tune_ccl_init_blocks));
 #define PB3D_CCL_INIT(CC, KK) hipLaunchKernelGGL((k_ccl_init<CC, KK>), ig, dim3(256), 0, ctx->stream, d_grid, rows, (int)A2, (int)P, K, cols, nwords, (u64*)bits, parent, lgR, zero_is_colour, nrec, shadow)
         if (C == 1) { if (KT == 1) PB3D_CCL_INIT(1, 1); else if (KT == 2) PB3D_CCL_INIT(1, 2); else if (KT == 4) PB3D_CCL_INIT(1, 4); else PB3D_CCL_INIT(1, 8); }
         else { if (KT == 1) PB3D_CCL_INIT(3, 1); else if (KT == 2) PB3D_CCL_INIT(3, 2); else if (KT == 4) PB3D_CCL_INIT(3, 4); else PB3D_CCL_INIT(3, 8); }

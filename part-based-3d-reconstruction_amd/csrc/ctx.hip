@@ -125,6 +125,15 @@ int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "ccl_blocks")) {
         PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: ccl_blocks is a count of workgroups per CU");
         ctx->tune_ccl_blocks = value;
+    } else if (!strcmp(name, "s32_order")) {
+        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: s32_order is 0 (plane groups fastest) or 1 (x fastest)");
+        ctx->tune_s32_order = value;
+    } else if (!strcmp(name, "s32_fuse_last")) {
+        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: s32_fuse_last is 0 (fused) or 1 (table step)");
+        ctx->tune_s32_fuse_last = value;
+    } else if (!strcmp(name, "ccl_init_blocks")) {
+        PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: ccl_init_blocks is a count of workgroups per CU");
+        ctx->tune_ccl_init_blocks = value;
     } else if (!strcmp(name, "ccl_tilecols")) {
         PB3D_REQUIRE(value >= 0 && value <= 64, "pb3d_set_tuning: ccl_tilecols is at most 64");
         ctx->tune_ccl_tilecols = value;

@@ -39,8 +39,11 @@ struct pb3d_ctx {
     int tune_rot90_wide;        // PB3D_ROT90_WIDE: 1 = the 256 x 256-tile form of the 90-degree step (development A/B)
     bool rot90w_lds_set;
     bool rot90wf_lds_set;       // ... and for its form on the rows' (y, z) streams (odd row lengths)
+    int tune_s32_order;         // knob "s32_order": 1 = the slice / un-slice passes walk x fastest (round 3's order; development A/B)
+    int tune_s32_fuse_last;     // knob "s32_fuse_last": 1 = the chain's last 90-degree step stays a table step (development A/B)
     int tune_s32_gpw;           // PB3D_S32_GPW: plane groups per workgroup of the sliced step kernel (0 = choose)
     int tune_ccl_blocks;        // knob "ccl_blocks": workgroups per CU of the labelling's last pass (0 = default)
+    int tune_ccl_init_blocks;   // knob "ccl_init_blocks": workgroups per CU of the labelling's first pass (0 = 16)
     int tune_ccl_tilecols;      // knob "ccl_tilecols": windows per level of a plane-to-plane merge tile (0 = 32)
     int tune_ccl_merge;         // knob "ccl_merge": 0 = tile kernels where the rows fit, 1 = always the pairwise kernel (development A/B)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
@@ -202,6 +205,7 @@ int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9]
                            u8* d_out);
 bool pb3d_generic_step_takes_src_mask(const double M[9], i64 W, i64 H, i64 D);
 bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D);
+int pb3d_perm_valid_table(pb3d_ctx* ctx, const double M[9], const double off[3], i64 W, i64 D, u32** bits, int* nw, int* c0, int* c2, bool* rot90);
 bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b);
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
                             const u8* d_mask_src, const u8* d_mask_dst, u8* d_out, const u8* d_rgb_hw3 = nullptr);

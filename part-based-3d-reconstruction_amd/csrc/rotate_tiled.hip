@@ -1536,6 +1536,15 @@ static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u3
     return PB3D_OK;
 }
 
+// the validity bit table of a permutation-like step for other translation units (csrc/sliced.hip: the chain's last step un-slices)
+int pb3d_perm_valid_table(pb3d_ctx* ctx, const double M[9], const double off[3], i64 W, i64 D, u32** bits, int* nw, int* c0, int* c2, bool* rot90) {
+    const RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
+    const PermMap pm = perm_map(M, off);
+    *c0 = pm.c0; *c2 = pm.c2;
+    *rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
+    return build_valid_table(ctx, p, W, D, bits, nw);
+}
+
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
                             const u8* d_mask_src, const u8* d_mask_dst, u8* d_out, const u8* d_rgb_hw3) {
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};

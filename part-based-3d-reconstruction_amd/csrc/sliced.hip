@@ -53,16 +53,26 @@ __global__ __launch_bounds__(256) void k_s32_maskbits(const u8* __restrict__ mas
 // u8 (W,H,D) -> S32.  One thread = 16 consecutive z of one (g, x): 32 planes x 16 bytes in (16-byte loads at whatever alignment the row
 // has), 16 dwords out.  mbits (optional): the 0-degree carve of process_voxel_grid (reference :111-124, first iteration) as a bit mask.
 typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+// WHOLE: D % 16 == 0, every thread's 16 voxels lie inside its row -- the loads are unconditional and all in flight together (a plane past
+// H re-reads the group's last plane, its bits are masked off).  Written with a branch per plane ("is it inside H", "is the piece
+// whole") every load sat in its own exec region with a wait behind it: 32 serial round trips per thread, 252 us at 1024^3.
+// NT: the grid is read with nontemporal loads -- at 1024^3 (1 GB read once) the pass went 252 -> ~200 us, at 512-class sizes (the grid
+// sits in the 256 MB memory-side cache from the kernel before) they cost 5 %: chosen by size.
+template <bool WHOLE, bool NT>
 __global__ __launch_bounds__(256) void k_s32_slice(const u8* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ mbits, i64 W, i64 H,
-                                                   i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total, int* __restrict__ flag) {
+                                                   i64 D, i64 Dp, pb3d_magic mzb, pb3d_magic mw, u32 total, int* __restrict__ flag, pb3d_magic mg, int gfast) {
     const u32 idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
-    const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
-    const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
+    // (gfast: consecutive wavefronts take consecutive plane groups of one x, their 32 KB source blocks following each other in memory,
+    // instead of blocks H * D bytes apart -- a development A/B that measured no difference)
+    const u32 r2 = pb3d_div(idx, mzb), zb = idx - r2 * mzb.d;
+    u32 g, x;
+    if (gfast) { x = pb3d_div(r2, mg); g = r2 - x * mg.d; } else { g = pb3d_div(r2, mw); x = r2 - g * mw.d; }
+    const u32 row = g * mw.d + x;
     const i64 z = 16 * (i64)zb;
     const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
     const u8* base = in + ((i64)x * H + 32 * (i64)g) * D + z;
-    const bool whole = z + 16 <= D;
+    const bool whole = WHOLE || z + 16 <= D;
     u32 hib = 0;
     u32 w[4][4];                    // w[k][j]: byte c = planes 8 k .. 8 k + 7 of voxel z + 4 j + c
 #pragma unroll
@@ -70,22 +80,22 @@ __global__ __launch_bounds__(256) void k_s32_slice(const u8* __restrict__ in, u3
         u32x4 d[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            d[q] = (u32x4)(0u);
-            if (8 * k + q < np) {
-                const u8* p = base + (i64)(8 * k + q) * D;
-                if (whole) d[q] = *(const u32x4_a1*)p;
-                else {
-                    u32 t4[4] = {0, 0, 0, 0};
-                    for (int b = 0; b < 16 && z + b < D; ++b) t4[b >> 2] |= (u32)p[b] << (8 * (b & 3));
-                    d[q].x = t4[0]; d[q].y = t4[1]; d[q].z = t4[2]; d[q].w = t4[3];
-                }
+            const int pl = 8 * k + q < np ? 8 * k + q : np - 1;
+            const u8* p = base + (i64)pl * D;
+            if (whole) d[q] = NT ? __builtin_nontemporal_load((const u32x4_a1*)p) : *(const u32x4_a1*)p;
+            else {
+                u32 t4[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16 && z + b < D; ++b) t4[b >> 2] |= (u32)p[b] << (8 * (b & 3));
+                d[q].x = t4[0]; d[q].y = t4[1]; d[q].z = t4[2]; d[q].w = t4[3];
             }
         }
         u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            a0 |= d[q].x << q; a1 |= d[q].y << q; a2 |= d[q].z << q; a3 |= d[q].w << q;
-            hib |= (d[q].x | d[q].y) | (d[q].z | d[q].w);
+            const u32 live = 8 * k + q < np ? 0xffffffffu : 0u;
+            const u32 dx = d[q].x & live, dy = d[q].y & live, dz = d[q].z & live, dw = d[q].w & live;
+            a0 |= dx << q; a1 |= dy << q; a2 |= dz << q; a3 |= dw << q;
+            hib |= (dx | dy) | (dz | dw);
         }
         w[k][0] = a0; w[k][1] = a1; w[k][2] = a2; w[k][3] = a3;
     }
@@ -104,17 +114,93 @@ __global__ __launch_bounds__(256) void k_s32_slice(const u8* __restrict__ in, u3
 
 // S32 -> u8 (W,H,D): the inverse, same thread shape
 __global__ __launch_bounds__(256) void k_s32_unslice(const u32* __restrict__ in, u8* __restrict__ out, i64 W, i64 H, i64 D, i64 Dp, pb3d_magic mzb,
-                                                     pb3d_magic mw, u32 total) {
+                                                     pb3d_magic mw, u32 total, pb3d_magic mg, int gfast) {
     const u32 idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
-    const u32 row = pb3d_div(idx, mzb), zb = idx - row * mzb.d;
-    const u32 g = pb3d_div(row, mw), x = row - g * mw.d;
+    const u32 r2 = pb3d_div(idx, mzb), zb = idx - r2 * mzb.d;
+    u32 g, x;
+    if (gfast) { x = pb3d_div(r2, mg); g = r2 - x * mg.d; } else { g = pb3d_div(r2, mw); x = r2 - g * mw.d; }
+    const u32 row = g * mw.d + x;
     const i64 z = 16 * (i64)zb;
     const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
     const u32* ip = in + (i64)row * Dp + z;
     u32 v[4][4];                    // v[j][k]: byte c = planes 8 k .. 8 k + 7 of voxel z + 4 j + c
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const u32x4 a = *(const u32x4*)(ip + 4 * j); tr4x4(a.x, a.y, a.z, a.w, v[j]); }
+    u8* base = out + ((i64)x * H + 32 * (i64)g) * D + z;
+    const bool whole = z + 16 <= D;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q >= np) continue;
+        u32x4 r;
+        r.x = (v[0][q >> 3] >> (q & 7)) & 0x01010101u; r.y = (v[1][q >> 3] >> (q & 7)) & 0x01010101u;
+        r.z = (v[2][q >> 3] >> (q & 7)) & 0x01010101u; r.w = (v[3][q >> 3] >> (q & 7)) & 0x01010101u;
+        u8* dp = base + (i64)q * D;
+        if (whole) *(u32x4_a1*)dp = r;
+        else {
+            const u32 t4[4] = {r.x, r.y, r.z, r.w};
+            for (int bb = 0; bb < 16 && z + bb < D; ++bb) dp[bb] = (u8)(t4[bb >> 2] >> (8 * (bb & 3)));
+        }
+    }
+}
+
+// The chain's LAST step, when it is the 90-degree one (every angle step that divides 90: reference :111 range(0, 91, k)), un-slices in its own
+// stores: out[x, y, z] = valid(x, z) && mask[x, y] ? S[c0 - z][y][x + c2] : 0 -- on 0/1 data a permutation-like step is the nearest tap
+// wherever SciPy's bounds test passes (DESIGN.md "Exactness of the permutation-like steps"; the bit table of k_rot_valid holds the
+// test's f64 verdicts).  One rotation sweep (0.35 GB at 1024^3) and one launch less per chain.  Workgroup = 32 x-rows x 128 z of one plane
+// group: the source block (128 S32 rows x 32 dwords = 128-byte pieces) is staged in LDS and read back transposed; a wave's plane store
+// covers 8 rows x 128 bytes.
+constexpr int UX = 32, UZ = 128, UPITCH = UX + 1;
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+
+__global__ __launch_bounds__(256) void k_s32_unslice90(const u32* __restrict__ in, u8* __restrict__ out, const u32* __restrict__ mbits,
+                                                       const u32* __restrict__ vbits, int nw, i64 W, i64 H, i64 D, i64 Dp, int c0, int c2, int ntz) {
+    __shared__ u32 tile[UZ * UPITCH];
+    const int tid = threadIdx.x;
+    const int t = (int)blockIdx.x, g = (int)blockIdx.y;
+    const i64 x0 = (i64)(t / ntz) * UX, z0 = (i64)(t % ntz) * UZ;
+    const u32* src = in + (i64)g * W * Dp;
+    // (loads without a branch around each: a row outside the volume re-reads row 0 and is masked; only workgroups at the volume's z-edge
+    // take the guarded path)
+    const bool inside = x0 + c2 >= 0 && x0 + c2 + UX <= Dp;         // wave-uniform
+    u32x4 dq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, r = idx >> 3, cg = idx & 7;
+        const i64 sx = (i64)c0 - (z0 + r), sz = x0 + c2 + 4 * cg;
+        const bool rowok = sx >= 0 && sx < W;
+        const u32* p = src + (rowok ? sx : 0) * Dp + sz;
+        if (inside) dq[k] = *(const u32x4_a4*)p;
+        else {
+            u32 d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sz + e >= 0 && sz + e < Dp) d[e] = p[e];
+            dq[k].x = d[0]; dq[k].y = d[1]; dq[k].z = d[2]; dq[k].w = d[3];
+        }
+        if (!rowok) dq[k] = (u32x4)(0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, r = idx >> 3, cg = idx & 7;
+        u32* dst = tile + r * UPITCH + 4 * cg;
+        dst[0] = dq[k].x; dst[1] = dq[k].y; dst[2] = dq[k].z; dst[3] = dq[k].w;
+    }
+    __syncthreads();
+    const int zp = tid & 7, xl = tid >> 3;
+    const i64 x = x0 + xl, z = z0 + 16 * zp;
+    if (x >= W || z >= D) return;
+    const u32 vb = (vbits[x * nw + (z >> 5)] >> (z & 31)) & 0xffffu;        // SciPy's bounds verdict of output cells (x, z .. z + 15)
+    const u32 m = mbits[(i64)g * W + x];
+    const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
+    u32 v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u32 a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = ((vb >> (4 * j + c)) & 1u) ? tile[(16 * zp + 4 * j + c) * UPITCH + xl] & m : 0u;
+        tr4x4(a[0], a[1], a[2], a[3], v[j]);
+    }
     u8* base = out + ((i64)x * H + 32 * (i64)g) * D + z;
     const bool whole = z + 16 <= D;
 #pragma unroll
@@ -212,6 +298,92 @@ __global__ __launch_bounds__(256) void k_s32_unslice_rgb(const u32* __restrict__
             const u32x4 t = win[wv][c];
             const i64 lb = __shfl((long long)mybase, L);
             if (lb >= 0) *(u32x4_a1*)(out + lb + 16 * part) = t;
+        }
+    }
+}
+
+// ... and for global_carve (reference :289-292): the last 90-degree step writes the COLOURS.  Same tile as k_s32_unslice90; a lane's 16
+// voxels are 48 bytes per plane, the eight lanes of an x-row hold 384 contiguous bytes: they pass through a wave-private LDS window and
+// leave in address order (lane zp stores the 16-byte chunks zp, 8 + zp, 16 + zp of its row), so a store instruction writes 8 rows x
+// 128 bytes.  Rows that end inside the tile (D % 128 != 0) are stored byte-wise.
+__global__ __launch_bounds__(256) void k_s32_unslice90_rgb(const u32* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ rgb_hw3,
+                                                           const u32* __restrict__ mbits, const u32* __restrict__ vbits, int nw, i64 W, i64 H, i64 D, i64 Dp,
+                                                           int c0, int c2, int ntz) {
+    __shared__ u32 tile[UZ * UPITCH];
+    __shared__ u32x4 win[4][192];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = (int)blockIdx.x, g = (int)blockIdx.y;
+    const i64 x0 = (i64)(t / ntz) * UX, z0 = (i64)(t % ntz) * UZ;
+    const u32* src = in + (i64)g * W * Dp;
+    const bool inside = x0 + c2 >= 0 && x0 + c2 + UX <= Dp;         // wave-uniform
+    u32x4 dq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, r = idx >> 3, cg = idx & 7;
+        const i64 sx = (i64)c0 - (z0 + r), sz = x0 + c2 + 4 * cg;
+        const bool rowok = sx >= 0 && sx < W;
+        const u32* p = src + (rowok ? sx : 0) * Dp + sz;
+        if (inside) dq[k] = *(const u32x4_a4*)p;
+        else {
+            u32 d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sz + e >= 0 && sz + e < Dp) d[e] = p[e];
+            dq[k].x = d[0]; dq[k].y = d[1]; dq[k].z = d[2]; dq[k].w = d[3];
+        }
+        if (!rowok) dq[k] = (u32x4)(0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, r = idx >> 3, cg = idx & 7;
+        u32* dst = tile + r * UPITCH + 4 * cg;
+        dst[0] = dq[k].x; dst[1] = dq[k].y; dst[2] = dq[k].z; dst[3] = dq[k].w;
+    }
+    __syncthreads();
+    const int zp = tid & 7, xl = tid >> 3;
+    const i64 x = x0 + xl, z = z0 + 16 * zp;
+    const bool rowlive = x < W;                                      // (the eight lanes of a row agree)
+    const bool live = rowlive && z < D;
+    const u32 vb = live ? (vbits[x * nw + (z >> 5)] >> (z & 31)) & 0xffffu : 0u;
+    const u32 m = rowlive ? mbits[(i64)g * W + x] : 0u;
+    const int np = (int)(H - 32 * (i64)g < 32 ? H - 32 * (i64)g : 32);
+    u32 v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u32 a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = ((vb >> (4 * j + c)) & 1u) ? tile[(16 * zp + 4 * j + c) * UPITCH + xl] & m : 0u;
+        tr4x4(a[0], a[1], a[2], a[3], v[j]);
+    }
+    const bool fullrow = z0 + UZ <= D;                               // block-uniform: every lane of a live row holds 16 voxels
+    const i64 rowbase = (((i64)(rowlive ? x : 0) * H + 32 * (i64)g) * D + z0) * 3;
+    const u8* px = rgb_hw3 + ((32 * (i64)g) * W + (rowlive ? x : 0)) * 3;
+    const int grp = (lane & ~7) * 3;                                  // this row's 24 chunks in the wave's window
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        if (q >= np) continue;
+        u32 o[12];
+        {
+            const u8* c = px + (i64)q * W * 3;
+            const u32 R = c[0], G = c[1], B = c[2];
+            const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rgb4((v[j][q >> 3] >> (q & 7)) & 0x01010101u, C0, C1, C2, o + 3 * j);
+        }
+        if (!fullrow) {
+            if (live) {
+                u8* dp = out + rowbase + (i64)q * D * 3 + 48 * zp;
+                for (int bb = 0; bb < 48 && 3 * z + bb < 3 * D; ++bb) dp[bb] = (u8)(o[bb >> 2] >> (8 * (bb & 3)));
+            }
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { u32x4 t4; t4.x = o[4 * k]; t4.y = o[4 * k + 1]; t4.z = o[4 * k + 2]; t4.w = o[4 * k + 3]; win[wv][3 * lane + k] = t4; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int cidx = 8 * k + zp;
+            const u32x4 t4 = win[wv][grp + cidx];
+            if (rowlive) *(u32x4_a1*)(out + rowbase + (i64)q * D * 3 + 16 * cidx) = t4;
         }
     }
 }
@@ -428,10 +600,14 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
     auto body = [&]() -> int {
         hipLaunchKernelGGL(k_s32_maskbits, dim3((unsigned)(((i64)G * W + 255) / 256)), dim3(256), 0, ctx->stream, d_mask_wh, W, H, G, (u32*)mb, flag);
         const u32 total = (u32)((i64)G * W * nzb);
-        const pb3d_magic mzb = pb3d_make_magic((u32)nzb), mw = pb3d_make_magic((u32)W);
+        const pb3d_magic mzb = pb3d_make_magic((u32)nzb), mw = pb3d_make_magic((u32)W), mg = pb3d_make_magic((u32)G);
+        const int gfast = ctx->tune_s32_order == 1;       // (measured: the order of the wavefronts makes no difference, 0.61 ms either way at 1024^3 / 45)
         if (d_occ) {
-            hipLaunchKernelGGL(k_s32_slice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, (const u32*)mb, W, H, D, Dp, mzb, mw,
-                               total, flag);
+            const bool nt = W * H * D >= (i64)256 << 20;
+#define PB3D_SLICE(WH, NTL) hipLaunchKernelGGL((k_s32_slice<WH, NTL>), dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, (const u32*)mb, W, H, D, Dp, mzb, mw, total, flag, mg, gfast)
+            if (D % 16 == 0) { if (nt) PB3D_SLICE(true, true); else PB3D_SLICE(true, false); }
+            else { if (nt) PB3D_SLICE(false, true); else PB3D_SLICE(false, false); }
+#undef PB3D_SLICE
         } else {
             const u32 tq = (u32)((i64)G * W * (Dp / 4));
             hipLaunchKernelGGL(k_s32_fill, dim3((tq + 255u) / 256u), dim3(256), 0, ctx->stream, (u32*)A, (const u32*)mb, D, Dp, pb3d_make_magic((u32)(Dp / 4)), tq);
@@ -450,8 +626,22 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
         PB3D_REQUIRE(nblk < (1ll << 31), "pb3d_process_grid: grid too large");
         u32 *src = (u32*)A, *dst = (u32*)B;
         bool checked = known_binary != 0;
-        for (int s0 = 0; s0 < nrot; s0 += SMAXSTEPS) {
-            const int ns = nrot - s0 < SMAXSTEPS ? nrot - s0 : SMAXSTEPS;
+        // the last step un-slices itself when it is the 90-degree one and a permutation of the cells (W + D even: integer offsets)
+        int nrot_tab = nrot;
+        u32* vbits = nullptr;
+        int vnw = 0, pc0 = 0, pc2 = 0;
+        if (nrot * angle_interval == 90 && ctx->tune_s32_fuse_last != 1 && H <= 65535ll * 32) {
+            double M[9], off[3];
+            PB3D_TRY(pb3d_rotinv(90, M));
+            PB3D_TRY(pb3d_offset(M, shape, off));
+            bool rot90 = false;
+            if (pb3d_is_perm_step(M, off, W, D)) {
+                PB3D_TRY(pb3d_perm_valid_table(ctx, M, off, W, D, &vbits, &vnw, &pc0, &pc2, &rot90));
+                if (rot90) nrot_tab = nrot - 1; else vbits = nullptr;
+            }
+        }
+        for (int s0 = 0; s0 < nrot_tab; s0 += SMAXSTEPS) {
+            const int ns = nrot_tab - s0 < SMAXSTEPS ? nrot_tab - s0 : SMAXSTEPS;
             memset(&sp, 0, sizeof(sp));
             for (int k = 0; k < ns; ++k) {
                 double M[9], off[3];
@@ -472,7 +662,7 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
                 PB3D_CHECK_LAUNCH();
                 static_assert(sizeof(sc.p) == sizeof(sp.p), "S32Cache holds one StepParams");
                 memcpy(sc.p, sp.p, sizeof(sp.p));
-                sc.W = W; sc.D = D; sc.ns = ns; sc.gen = ctx->scratch_gen; sc.valid = nrot <= SMAXSTEPS;
+                sc.W = W; sc.D = D; sc.ns = ns; sc.gen = ctx->scratch_gen; sc.valid = nrot_tab <= SMAXSTEPS;
             }
             if (!checked) {                                            // the slice kernel's verdict (the table build is queued behind it meanwhile)
                 PB3D_HIP(hipEventSynchronize(ctx->s32_ev));
@@ -486,11 +676,24 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
             }
             PB3D_CHECK_LAUNCH();
         }
-        if (d_rgb_hw3)
+        if (nrot_tab == 0 && !checked) {                                  // (a chain of ONE fused step: the slice kernel's verdict is still out)
+            PB3D_HIP(hipEventSynchronize(ctx->s32_ev));
+            checked = true;
+            if (*hflag != 0) return PB3D_EUNSUPPORTED;
+        }
+        if (vbits && d_rgb_hw3) {
+            const int utz = (int)((D + UZ - 1) / UZ), utx = (int)((W + UX - 1) / UX);
+            hipLaunchKernelGGL(k_s32_unslice90_rgb, dim3((unsigned)(utz * utx), (unsigned)G), dim3(256), 0, ctx->stream, (const u32*)src, d_out, d_rgb_hw3,
+                               (const u32*)mb, (const u32*)vbits, vnw, W, H, D, Dp, pc0, pc2, utz);
+        } else if (vbits) {
+            const int utz = (int)((D + UZ - 1) / UZ), utx = (int)((W + UX - 1) / UX);
+            hipLaunchKernelGGL(k_s32_unslice90, dim3((unsigned)(utz * utx), (unsigned)G), dim3(256), 0, ctx->stream, (const u32*)src, d_out, (const u32*)mb,
+                               (const u32*)vbits, vnw, W, H, D, Dp, pc0, pc2, utz);
+        } else if (d_rgb_hw3)
             hipLaunchKernelGGL(k_s32_unslice_rgb, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, d_rgb_hw3, W, H, D, Dp, mzb, mw,
                                total);
         else
-            hipLaunchKernelGGL(k_s32_unslice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, W, H, D, Dp, mzb, mw, total);
+            hipLaunchKernelGGL(k_s32_unslice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, W, H, D, Dp, mzb, mw, total, mg, gfast);
         PB3D_CHECK_LAUNCH();
         return PB3D_OK;
     };

@@ -27,10 +27,13 @@ d_bhw = dev.DeviceBuffer(S * S); d_rgb = dev.DeviceBuffer(S * S * 3); d_mwh = de
 dev.synth_mask16(S, d_binary_hw=d_bhw, d_rgb_hw3=d_rgb, d_binary_wh=d_mwh)
 d_col = dev.DeviceBuffer(S ** 3 * 3)
 for ai in (int(v) for v in a.intervals.split(",")):
-    res = {0: [], 1: []}
+    # sliced: the last 90-degree step writes the colours itself; sliced_unfused_last: table step + separate colour un-slicing (round 3's form)
+    modes = {"sliced": (0, 0), "sliced_unfused_last": (0, 1), "bytes": (1, 0)}
+    res = {m: [] for m in modes}
     for r in range(a.rounds):
-        for mode in (0, 1):
-            pb3d._lib.set_tuning("sliced", mode)
-            res[mode].append(round(timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, ai, d_col), 3), 4))
-    pb3d._lib.set_tuning("sliced", 0)
-    print(json.dumps({"size": S, "interval": ai, "rotation_steps": 90 // ai, "ms_sliced": res[0], "ms_bytes": res[1]}), flush=True)
+        for m, (sl, fl) in modes.items():
+            pb3d._lib.set_tuning("sliced", sl); pb3d._lib.set_tuning("s32_fuse_last", fl)
+            res[m].append(round(timeit(lambda: dev.global_carve(d_bhw, d_rgb, S, S, ai, d_col), 3), 4))
+    pb3d._lib.set_tuning("sliced", 0); pb3d._lib.set_tuning("s32_fuse_last", 0)
+    print(json.dumps({"size": S, "interval": ai, "rotation_steps": 90 // ai, "ms_sliced": res["sliced"], "ms_sliced_unfused_last": res["sliced_unfused_last"],
+                      "ms_bytes": res["bytes"]}), flush=True)

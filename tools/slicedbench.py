@@ -25,7 +25,10 @@ def main():
     ap.add_argument("--intervals", default="5,45")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tune", default="", help="development knobs, e.g. s32_order=1")
     a = ap.parse_args()
+    for kv in [t for t in a.tune.split(',') if t]:
+        pb3d._lib.set_tuning(kv.split('=')[0], int(kv.split('=')[1]))
     rng = np.random.default_rng(5)
     for sh in a.shapes.split(","):
         W, H, D = (int(v) for v in sh.split("x"))
@@ -34,20 +37,24 @@ def main():
         d_occ = dev.DeviceBuffer(nvox); d_o = dev.DeviceBuffer(nvox); d_t = dev.DeviceBuffer(nvox)
         dev.synth_occ(0, W, H, D, 0, d_occ)
         for ai in (int(v) for v in a.intervals.split(",")):
-            res = {0: [], 1: []}
+            # modes: the bit-sliced chain (its last 90-degree step un-slices in its own stores), the same with the last step as a table
+            # step + a separate un-slicing pass (round 3's form), the byte chain
+            modes = {"sliced": (0, 0), "sliced_unfused_last": (0, 1), "bytes": (1, 0)}
+            res = {m: [] for m in modes}
             outs = {}
             for r in range(a.rounds):
-                for mode in (0, 1):
-                    pb3d._lib.set_tuning("sliced", mode)
-                    res[mode].append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, ai, d_o, d_t), a.reps), 4))
+                for m, (sl, fl) in modes.items():
+                    pb3d._lib.set_tuning("sliced", sl); pb3d._lib.set_tuning("s32_fuse_last", fl)
+                    res[m].append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, ai, d_o, d_t), a.reps), 4))
                     if r == 0:
-                        outs[mode] = d_o.download((W, H, D)) if nvox <= 1 << 28 else None
-            pb3d._lib.set_tuning("sliced", 0)
-            same = None if outs[0] is None else bool(np.array_equal(outs[0], outs[1]))
+                        outs[m] = d_o.download((W, H, D))
+            pb3d._lib.set_tuning("sliced", 0); pb3d._lib.set_tuning("s32_fuse_last", 0)
+            same = bool(np.array_equal(outs["sliced"], outs["bytes"]) and np.array_equal(outs["sliced_unfused_last"], outs["bytes"]))
+            outs = None
             nrot = 90 // ai
-            print(json.dumps({"shape": [W, H, D], "interval": ai, "rotation_steps": nrot, "ms_sliced": res[0], "ms_bytes": res[1],
-                              "per_step_us_sliced": round(1e3 * min(res[0]) / nrot, 1), "per_step_us_bytes": round(1e3 * min(res[1]) / nrot, 1),
-                              "results_equal": same}), flush=True)
+            print(json.dumps({"shape": [W, H, D], "interval": ai, "rotation_steps": nrot, "ms_sliced": res["sliced"], "ms_sliced_unfused_last": res["sliced_unfused_last"],
+                              "ms_bytes": res["bytes"], "per_step_us_sliced": round(1e3 * min(res["sliced"]) / nrot, 1),
+                              "per_step_us_bytes": round(1e3 * min(res["bytes"]) / nrot, 1), "results_equal": same}), flush=True)
         for b in (d_mwh, d_occ, d_o, d_t):
             b.free()
 
