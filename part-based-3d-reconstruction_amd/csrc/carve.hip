@@ -686,11 +686,9 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
             const int j = jl.j[k];
             const u8* ms = d_mask_sub + (i64)j * W * H;
             const u8* mc = d_mask_carve + (i64)j * W * H;
-            PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));      // tables of the job's first rotation, behind the kernels below
             hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, mD);
             PB3D_CHECK_LAUNCH();
             PB3D_TRY(pb3d_process_grid_binary_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carvedN + (i64)k * nvox, (u8*)tmp));
-            if (k + 1 < jl.n) PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jl.j[k + 1]]));
         }
         hipLaunchKernelGGL(k_sub_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, jl, W * H, (u32*)S);
         PB3D_CHECK_LAUNCH();
@@ -708,7 +706,6 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
         if (job_skip[j]) continue;
         const u8* ms = d_mask_sub + (i64)j * W * H;
         const u8* mc = d_mask_carve + (i64)j * W * H;
-        PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));          // tables of the job's first rotation, behind the kernels below
         if (wide) {
             hipLaunchKernelGGL(k_part_occ16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)d_colored, ms, (u32x4*)occ, ngroups, mD);
             if (vtail < nvox) hipLaunchKernelGGL(k_part_occ, dim3(1), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D, vtail);
@@ -716,8 +713,6 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
             hipLaunchKernelGGL(k_part_occ, dim3(blocks), dim3(256), 0, ctx->stream, d_colored, ms, (u8*)occ, nvox, D);
         PB3D_CHECK_LAUNCH();
         PB3D_TRY(pb3d_process_grid_binary_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
-        for (int jn = j + 1; jn < njobs; ++jn)                                  // ... and of the next job's, behind this job's last kernels
-            if (!job_skip[jn]) { PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jn])); break; }
         if (wide) {
             hipLaunchKernelGGL(k_keep_or16, dim3(gblocks), dim3(256), 0, ctx->stream, (const u32x4*)carved, ms, (u32x4*)keep, ngroups, mD, any ? 0 : 1);
             if (vtail < nvox) hipLaunchKernelGGL(k_keep_or, dim3(1), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, vtail);

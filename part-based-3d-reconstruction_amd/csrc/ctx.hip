@@ -55,8 +55,6 @@ int pb3d_create(int device, pb3d_ctx** out) {
     ctx->device = device;
     {
         auto env_int = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; };
-        ctx->tune_rotate_tile = env_int("PB3D_ROTATE_TILE");
-        ctx->tune_rot8_ty = env_int("PB3D_ROT8_TY");
         const char* names[6] = {"PB3D_TUNE0", "PB3D_TUNE1", "PB3D_TUNE2", "PB3D_TUNE3", "PB3D_TUNE4", "PB3D_TUNE5"};
         for (int i = 0; i < 6; ++i) ctx->tune_misc[i] = env_int(names[i]);
         ctx->tune_uncap = env_int("PB3D_UNCAP");
@@ -78,16 +76,11 @@ int pb3d_create(int device, pb3d_ctx** out) {
         pb3d_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         return PB3D_ENODEVICE;
     }
-    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipEventCreateWithFlags(&ctx->rot_cache[k].ready, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->rot_cache[k].used, hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->s32_ev, hipEventDisableTiming);
+    e = hipEventCreateWithFlags(&ctx->s32_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         free(ctx);
-        pb3d_set_error("creating the auxiliary stream failed: %s", hipGetErrorString(e));
+        pb3d_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
         return PB3D_ENODEVICE;
     }
     {
@@ -108,14 +101,8 @@ int pb3d_create(int device, pb3d_ctx** out) {
 
 int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     PB3D_REQUIRE(ctx != nullptr && name != nullptr, "pb3d_set_tuning: null argument");
-    if (!strcmp(name, "rotate_tile")) {
-        PB3D_REQUIRE(value == 0 || value == 64 || value == 128 || value == 256, "pb3d_set_tuning: rotate_tile is 0, 64, 128 or 256");
-        ctx->tune_rotate_tile = value;
-    } else if (!strcmp(name, "rot8_ty")) {
-        PB3D_REQUIRE(value >= 0 && value % 8 == 0, "pb3d_set_tuning: rot8_ty is a multiple of 8");
-        ctx->tune_rot8_ty = value;
-    } else if (!strcmp(name, "sliced")) {
-        PB3D_REQUIRE(value >= 0 && value <= 2, "pb3d_set_tuning: sliced is 0 (chains), 1 (never) or 2 (single steps too)");
+    if (!strcmp(name, "sliced")) {
+        PB3D_REQUIRE(value >= 0 && value <= 1, "pb3d_set_tuning: sliced is 0 (rotation steps on 0/1 data run bit-sliced) or 1 (never: byte chain)");
         ctx->tune_sliced = value;
     } else if (!strcmp(name, "rot90_wide")) {
         ctx->tune_rot90_wide = value;
@@ -159,16 +146,13 @@ void pb3d_destroy(pb3d_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->aux_stream);
     pb3d_comm_destroy(ctx);
     (void)pool_flush(ctx);
     for (int i = 0; i < PB3D_NSCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
-    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(ctx->rot_cache[k].ready); (void)hipEventDestroy(ctx->rot_cache[k].used); }
     (void)hipEventDestroy(ctx->s32_ev);
-    (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -394,7 +378,6 @@ int pb3d_scratch(pb3d_ctx* ctx, int slot, size_t bytes, void** out) {
     if (ctx->scratch_bytes[slot] < bytes || !ctx->scratch[slot]) {
         if (ctx->scratch[slot]) {
             PB3D_TRY(pb3d_stream_sync(ctx));
-            PB3D_HIP(hipStreamSynchronize(ctx->aux_stream));
             PB3D_HIP(hipFree(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;
             ctx->scratch_bytes[slot] = 0;

@@ -33,64 +33,26 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     const i64 W = w, H = h, D = w, nvox = W * H * D;
     if (nvox == 0 || x1 == x0) return PB3D_OK;
     PB3D_REQUIRE(d_bin_hw && d_rgb_hw3 && d_out_slab, "pb3d_global_carve: null buffer");
+    const i64 shape[3] = {W, H, D};
     if (angle_interval == 90 && W <= 4096) {
         // angles [0, 90]: both steps are exact permutations on a (w,h,w) grid -> one write-only kernel
-        const i64 shape[3] = {W, H, D};
         double M[9], off[3];
         PB3D_TRY(pb3d_rotinv(90, M));
         PB3D_TRY(pb3d_offset(M, shape, off));
         if (pb3d_is_perm_step(M, off, W, D)) return pb3d_launch_global_carve90(ctx, d_bin_hw, d_rgb_hw3, h, w, M, off, x0, x1, d_out_slab);
     }
-    // Other angle steps: the chain of process_voxel_grid on a grid that never exists in its first and last form.  Step 0 (the
-    // mask carve of the all-ones grid) and step 1 are ONE write-only kernel that synthesises its source from the mask
-    // (k_first_step); the last step, when it is the exact 90-degree permutation, writes the colours itself (k_rot90<RGBOUT>).
-    // 45: first + 90/colour = 1 B written, 1 B read, 3 B written per voxel (was: memset, two full steps, colour apply = 9 B).
-    // 60 (one rotation): a single write-only 3 B/voxel kernel.  Slab outputs need the fused 90-degree path above.
+    // Other angle steps: the chain of process_voxel_grid on a grid that never exists as bytes before its final (W,H,D,3) form -- the mask
+    // bits are written as the bit-sliced volume, the rotation steps run on it, the last one writes the colours (csrc/sliced.hip).
+    // Slab outputs need the fused 90-degree path above.
     PB3D_REQUIRE(x0 == 0 && x1 == W, "pb3d_global_carve: slab output needs the fused 90-degree path (angle_interval=90, w %% 16 == 0)");
     const int nsteps = 90 / angle_interval + 1;  // len(range(0, 91, k))
     void* mwh;
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));
     PB3D_TRY(pb3d_transpose_mask_dev(ctx, d_bin_hw, H, W, (u8*)mwh));
-    const i64 shape[3] = {W, H, D};
-    if (nsteps >= 3 && ctx->tune_misc[3] != 1) {                    // two and more rotation steps: bit-sliced from the mask to the colours
+    if (nsteps >= 2 && ctx->tune_misc[3] != 1) {                    // tune misc3 = 1: the composed pipeline (parity tests run both)
         int took = 0;
         PB3D_TRY(pb3d_global_carve_sliced(ctx, (const u8*)mwh, d_rgb_hw3, W, H, D, angle_interval, d_out_slab, &took));
         if (took) return PB3D_OK;
-    }
-    if (nsteps >= 2 && ctx->tune_misc[3] != 1) {                    // tune misc3 = 1: the composed pipeline (parity tests run both)
-        double M1[9], off1[3];
-        PB3D_TRY(pb3d_rotinv(angle_interval, M1));
-        PB3D_TRY(pb3d_offset(M1, shape, off1));
-        if (!pb3d_is_perm_step(M1, off1, W, D)) {
-            if (nsteps == 2) {
-                const int rc = pb3d_launch_first_step(ctx, W, H, D, M1, off1, (const u8*)mwh, d_rgb_hw3, d_out_slab);
-                if (rc != PB3D_EUNSUPPORTED) return rc;
-            } else {
-                void *a, *b;
-                PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &a));
-                PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &b));
-                int rc = pb3d_launch_first_step(ctx, W, H, D, M1, off1, (const u8*)mwh, nullptr, (u8*)a);
-                if (rc != PB3D_EUNSUPPORTED) {
-                    PB3D_TRY(rc);
-                    u8 *src = (u8*)a, *dst = (u8*)b;
-                    for (int st = 2; st < nsteps; ++st) {
-                        double M[9], off[3];
-                        PB3D_TRY(pb3d_rotinv(st * angle_interval, M));
-                        PB3D_TRY(pb3d_offset(M, shape, off));
-                        const bool last = st == nsteps - 1;
-                        const bool perm = pb3d_perm_step_ok(M, off, W, D, src, dst);
-                        const bool rot90 = perm && nearbyint(M[0]) == 0 && nearbyint(M[2]) == -1 && nearbyint(M[6]) == 1 && nearbyint(M[8]) == 0;
-                        if (last && rot90 && D % 16 == 0 && ((i64)nearbyint(off[2])) % 16 == 0 && (((uintptr_t)d_out_slab) & 15u) == 0 && W <= 65535 * 128 &&
-                            H <= 65535)
-                            return pb3d_launch_rotate_perm(ctx, src, W, H, D, M, off, nullptr, (const u8*)mwh, d_out_slab, d_rgb_hw3);
-                        if (perm) PB3D_TRY(pb3d_launch_rotate_perm(ctx, src, W, H, D, M, off, nullptr, (const u8*)mwh, dst));
-                        else PB3D_TRY(pb3d_launch_rotate_generic(ctx, src, W, H, D, M, off, (const u8*)mwh, dst, nullptr));
-                        u8* t = src; src = dst; dst = t;
-                    }
-                    return pb3d_color_apply_dev(ctx, src, W, H, D, d_rgb_hw3, d_out_slab);
-                }
-            }
-        }
     }
     // composed pipeline: ones -> process_voxel_grid -> colour
     void *ones, *carved, *tmp;

@@ -356,13 +356,10 @@ int pb3d_part_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_label, int64_t W, 
         if (job_skip[j]) continue;
         const u8* ms = d_mask_sub + (i64)j * W * H;
         const u8* mc = d_mask_carve + (i64)j * W * H;
-        PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[j]));          // tables of the job's first rotation, behind the kernels below
         if (wide) hipLaunchKernelGGL(k_label_occ<16>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D, mDl, smalll);
         else hipLaunchKernelGGL(k_label_occ<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_label, ms, (u8*)occ, nvox, D, mDl, smalll);
         PB3D_CHECK_LAUNCH();
         PB3D_TRY(pb3d_process_grid_binary_dev(ctx, (const u8*)occ, W, H, D, mc, job_angle[j], (u8*)carved, (u8*)tmp));
-        for (int jn = j + 1; jn < njobs; ++jn)                                  // ... and of the next job's, behind this job's last kernels
-            if (!job_skip[jn]) { PB3D_TRY(pb3d_prefetch_first_step(ctx, W, H, D, job_angle[jn])); break; }
         if (wide) hipLaunchKernelGGL(k_label_keep_or<16>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, mDl, smalll);
         else hipLaunchKernelGGL(k_label_keep_or<1>, dim3(blocks), dim3(256), 0, ctx->stream, (const u8*)carved, ms, (u8*)keep, nvox, D, any ? 0 : 1, mDl, smalll);
         PB3D_CHECK_LAUNCH();

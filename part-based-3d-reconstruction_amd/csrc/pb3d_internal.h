@@ -26,16 +26,12 @@ struct pb3d_ctx {
     int device;
     int cus;
     hipStream_t stream;
-    bool wide_lds_set;          // hipFuncSetAttribute(max dynamic LDS) done for the wide rotate kernel on this device
-    bool packed_lds_set;        // ... and for the packed 256-tile one
     bool orient_lds_set;        // ... and for the 128-pixel orientation kernel (csrc/components.hip)
     bool guided_lds_set;        // ... and for the crop-chain kernel of left_right_guided_carve (csrc/guided.hip)
     // development knobs, read from the environment ONCE in pb3d_create (never on a launch path)
-    int tune_rotate_tile;       // PB3D_ROTATE_TILE: 0 = choose, 64 / 128 / 256 = pin the generic-angle tile kernel
-    int tune_rot8_ty;           // PB3D_ROT8_TY: planes per workgroup of the packed kernel (0 = default)
     int tune_misc[6];           // PB3D_TUNE0..5: experiment switches of kernels under development
     int tune_uncap;             // PB3D_UNCAP=1: every grid-stride kernel gets one workgroup per tile (A/B of the persistent grids)
-    int tune_sliced;            // PB3D_SLICED: 0 = chains of >= 2 rotation steps run bit-sliced (csrc/sliced.hip), 1 = never, 2 = also single steps
+    int tune_sliced;            // PB3D_SLICED: 0 = rotation steps on 0/1 data run bit-sliced (csrc/sliced.hip), 1 = never (byte chain, arithmetic kernel)
     int tune_rot90_wide;        // PB3D_ROT90_WIDE: 1 = the 256 x 256-tile form of the 90-degree step (development A/B)
     bool rot90w_lds_set;
     bool rot90wf_lds_set;       // ... and for its form on the rows' (y, z) streams (odd row lengths)
@@ -71,22 +67,6 @@ struct pb3d_ctx {
         i64 X, Y, Z, n;
         bool valid;
     } deform;
-    // Tables of generic-angle steps (csrc/rotate.hip: launch_table_step): TWO sets of scratch slots.  A step finds its tables where
-    // an earlier call left them (same key), or where pb3d_prefetch_rotation built them on the auxiliary stream while the previous
-    // step's kernel was running -- the tables depend on (matrix, offset, shape) only, never on data.
-    struct RotCache {
-        int kind;               // 0: nothing cached
-        i64 W, H, D;
-        void* cells;
-        u64 gen;                // scratch_gen when the tables were built
-        double p[8];
-        u64 stamp;              // last use / build (the older set is rebuilt)
-        bool pending_aux;       // built on aux_stream: the main stream has not waited for `ready` yet
-        hipEvent_t ready;       // recorded on aux_stream after a prefetch
-        hipEvent_t used;        // recorded on the main stream after the last kernel that read this set
-        bool used_valid;
-    } rot_cache[2];
-    u64 rot_stamp;
     struct ValidCache { void* buf; u64 gen; i64 W, D; double p[8]; } valid_cache;   // validity bit table of the last 90-degree step (scratch slot 10)
     // Tile programs of the bit-sliced chain (csrc/sliced.hip, scratch slot 32): valid for these steps on this (W, D)
     struct S32Cache { bool valid; u64 gen; i64 W, D; int ns; double p[32 * 8]; } s32_cache;
@@ -95,9 +75,6 @@ struct pb3d_ctx {
     // of colour k (K colours labelled together, csrc/ccl.hip: their numbering is per colour, so a label needs its colour's bits to mean anything
     // once K > 1).  gen = scratch_slot_gen[42] when the bits were written: only a reallocation of THAT slot invalidates them.
     struct CclLast { bool valid; const void* labels; const void* bits; i64 rows, A2, P; u64 gen; bool members_only; int K, C; u32 colors[PB3D_CCL_MAX_COLORS]; } ccl_last;
-    void* flag_ring;            // the ring of "value > 1 seen" flag words of the generic-angle steps (scratch slot 15) and its position
-    u64 flag_gen;
-    hipStream_t aux_stream;     // table builds that overlap the main stream's kernels
     // Device block pool behind pb3d_dev_alloc / pb3d_dev_free: a freed block is kept (no hipFree, no stream synchronisation) and handed
     // to the next request of about its size.  Everything that touches such a block runs on ctx->stream, in order, so a re-used block
     // is never written before its previous reader has finished.  The NumPy-signature API allocates and frees a volume-sized buffer
@@ -195,20 +172,17 @@ int pb3d_global_carve_sliced(pb3d_ctx* ctx, const u8* d_mask_wh, const u8* d_rgb
 // pb3d_process_grid_dev for callers whose grid is 0/1 by construction (occupancy of a colour grid, all-ones): no host wait
 int pb3d_process_grid_binary_dev(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out,
                                  u8* d_tmp);
-// queue the table build of a LATER generic-angle step on the auxiliary stream (no-op when the step has no tables or they exist)
-int pb3d_prefetch_rotation(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3]);
-// ... of the first rotation of process_voxel_grid(., ., angle_interval)
-int pb3d_prefetch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, int angle_interval);
+// one rotation step with the caller's matrix through the bit-sliced path (csrc/sliced.hip); *took = 0: not applicable
+int pb3d_rotate_step_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const double M[9], const double off[3], const u8* d_mask_wh, u8* d_out,
+                            int* took);
+// the arithmetic kernel (csrc/rotate.hip): any uint8 data, any rotation about Y
 int pb3d_launch_rotate_generic(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9],
                                const double off[3], const u8* d_mask_wh, u8* d_out, const u8* d_mask_src);
-int pb3d_launch_first_step(pb3d_ctx* ctx, i64 W, i64 H, i64 D, const double M[9], const double off[3], const u8* d_mask_wh, const u8* d_rgb_hw3,
-                           u8* d_out);
-bool pb3d_generic_step_takes_src_mask(const double M[9], i64 W, i64 H, i64 D);
 bool pb3d_is_perm_step(const double M[9], const double off[3], i64 W, i64 D);
 int pb3d_perm_valid_table(pb3d_ctx* ctx, const double M[9], const double off[3], i64 W, i64 D, u32** bits, int* nw, int* c0, int* c2, bool* rot90);
 bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b);
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
-                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out, const u8* d_rgb_hw3 = nullptr);
+                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out);
 int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
                           const int* job_angle, const int* job_skip, int njobs, u8* d_out);
 int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh);

@@ -372,39 +372,29 @@ __device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_
 // transpose) is 0.455 ms, a linear copy with the same workgroup shape 0.41 ms.
 // RAGGED = false: D % 16 == 0 and c2 % 16 == 0, every piece is whole and the byte-wise paths are compiled out (they cost
 // 25 % at 1024^3 when merely present)
-// RGBOUT (with RAGGED = false): the step is the LAST one of a global_carve chain (reference utils/voxel_carving_utils.py:279-292) --
-// instead of the 0/1 occupancy byte, voxel (x,y,z) gets the colour rgb_hw3[y, x] where the byte is 1 (apply_colored_mask_to_voxel_grid
-// :128-136 folded into the store: 48 bytes per 16 voxels, no occupancy volume written or re-read).
-// ALIGNZ (with RAGGED): rows that are not multiples of 128 bytes, on grids with H * D % 128 == 0 -- every real shape of the reference
-// whose LONGER mask side is the height (max_dim = 128 / 256 / 512 makes H a multiple of 128; Charminar 355 x 512 x 355).  All rows
-// (x, y) of one plane then start at the same phase phi(y) = (address of row (0, y)) mod 128, so the tile grid of plane y is shifted
-// by -phi(y) along z: in the shifted coordinate z' = z + phi(y) every output piece is an ALIGNED 16 bytes and every 8-lane row
-// segment a whole 128-byte line (unshifted, each segment straddles two lines and every line is written twice, by two workgroups).
-// Only c0 (source row = c0 + phi - z'), the validity window and the two clipped pieces at a row's ends depend on the plane.
-template <int DEPTH, bool RAGGED, bool RGBOUT = false, bool ALIGNZ = false>
+// (Round 4: the colour-writing and plane-shifted forms of this kernel are gone -- global_carve chains write their colours from the
+// bit-sliced volume, csrc/sliced.hip, and rows that are not whole lines take the flat kernels below.)
+template <int DEPTH, bool RAGGED>
 __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict__ in, u8* __restrict__ out, const u8* __restrict__ mask_src,
                                                const u8* __restrict__ mask_dst, const u32* __restrict__ vbits, int nw, int c0, int c2,
-                                               i64 W, i64 H, i64 D, int TY, TileMap tm, const u8* __restrict__ rgb_hw3 = nullptr) {
+                                               i64 W, i64 H, i64 D, int TY, TileMap tm) {
     __shared__ __attribute__((aligned(16))) u8 tiles[2][128 * 128];
-    __shared__ u32x4 xch[RGBOUT ? 4 * 192 : 1];        // RGBOUT: wave-private exchange window of the colour stores (see below)
     const int tid = threadIdx.x;
     i64 zt, xt, yc;
     if (!tile_of_block(tm, &zt, &xt, &yc)) return;                          // whole workgroup, before any barrier
     const i64 x0 = xt * 128, z0 = zt * 128;
     const i64 y_beg = yc * TY;
     const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
-    // phase of plane y's rows (ALIGNZ): the same for every x because H * D % 128 == 0
-    auto phi = [&](i64 y) -> i64 { return ALIGNZ ? (i64)(((uintptr_t)out + (uintptr_t)(y * D)) & 127u) : 0; };
     // staging role: local source row lr = (tid >> 3) + 32 j, 16-byte block cb = tid & 7
     const int cb = tid & 7;
-    const i64 rbase0 = (i64)c0 - (z0 + 127);            // source row of local row 0 (+ phi(y) under ALIGNZ)
+    const i64 rbase0 = (i64)c0 - (z0 + 127);            // source row of local row 0
     const i64 scol = x0 + c2 + 16 * cb;                 // source column of this thread's block
     const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
     // output role: z-run zg = tid & 7 (16 z), x-group xg = tid >> 3 (4 x)
     const int zg = tid & 7, xg = tid >> 3;
     const int g = 7 - zg;                               // row group holding this thread's 16 source rows
     const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
-    const i64 zo = z0 + 16 * zg;                          // z' of this thread's run; z = zo - phi(y)
+    const i64 zo = z0 + 16 * zg;                          // first z of this thread's run
     // 16 validity bits of row x for z = zlo .. zlo + 15 (zero outside [0, D): the table is zero there, negative z are shifted out)
     auto vwin = [&](i64 x, i64 zlo) -> u32 {
         if (x >= W || zlo <= -16 || zlo >= D) return 0u;
@@ -416,20 +406,15 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
     };
     u32 vb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vb[i] = ALIGNZ ? 0xffffu : vwin(x0 + 4 * xg + i, zo);
+    for (int i = 0; i < 4; ++i) vb[i] = vwin(x0 + 4 * xg + i, zo);
     // Everything a plane needs from global memory is issued together, DEPTH planes ahead: the 16-byte source pieces, the
     // source-row mask bytes (applied when the data lands, so the two loads are not dependent) and the
     // destination-row mask bytes.
     u32x4 stg[DEPTH][4];
     u32 msk[DEPTH];    // bit j: source-row mask of piece j ; bits 4..7: destination-row mask of row i
-    u32 vbn[DEPTH][ALIGNZ ? 4 : 1];   // ALIGNZ: the plane's own validity windows (z = zo - phi(y)), fetched with the plane's data
-    auto load_plane = [&](u32x4 (&sg)[4], u32& mkout, u32 (&vn)[ALIGNZ ? 4 : 1], i64 y) {
+    auto load_plane = [&](u32x4 (&sg)[4], u32& mkout, i64 y) {
         u32 mk = 0;
-        const i64 rbase = rbase0 + phi(y);
-        if (ALIGNZ) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vn[i] = y < y_end ? vwin(x0 + 4 * xg + i, zo - phi(y)) : 0u;
-        }
+        const i64 rbase = rbase0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const i64 n0 = rbase + (tid >> 3) + 32 * j;
@@ -451,12 +436,12 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const i64 x = x0 + 4 * xg + i;
-            if (y < y_end && x < W && (ALIGNZ ? vn[i] : vb[i])) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
+            if (y < y_end && x < W && vb[i]) mk |= (u32)((mask_dst ? mask_dst[x * H + y] : (u8)1) != 0) << (4 + i);
         }
         mkout = mk;
     };
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) load_plane(stg[s], msk[s], vbn[s], y_beg + s);
+    for (int s = 0; s < DEPTH; ++s) load_plane(stg[s], msk[s], y_beg + s);
     int buf = 0;
     for (i64 y0p = y_beg; y0p < y_end; y0p += DEPTH) {
 #pragma unroll
@@ -472,10 +457,7 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = ((mkc >> j) & 1u) ? stg[s][j] : (u32x4)(0u);
             }
             __syncthreads();      // the only barrier of the plane: the other tile buffer was last read before the previous one
-            u32 vcur[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vcur[i] = ALIGNZ ? vbn[s][i] : vb[i];
-            load_plane(stg[s], msk[s], vbn[s], y + DEPTH);
+            load_plane(stg[s], msk[s], y + DEPTH);
             u32 d[16];
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
@@ -490,17 +472,15 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                 o[2][w] = perm(u1, t1, 0x05040100u);
                 o[3][w] = perm(u1, t1, 0x07060302u);
             }
-            const i64 ph = phi(y), zlo = zo - ph;                     // this run's true z range is zlo .. zlo + 15
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const i64 x = x0 + 4 * xg + i;
-                const bool act = !(x >= W || zlo >= D || (ALIGNZ && zlo <= -16));
-                if (!RGBOUT && !act) continue;          // (RGBOUT: every lane takes part in the exchange below)
-                const u32 vbi = vcur[i];
+                if (x >= W || zo >= D) continue;
+                const u32 vbi = vb[i];
                 u32x4 r = (u32x4)(0u);
                 if ((mkc >> (4 + i)) & 1u) {
                     r.x = o[i][0]; r.y = o[i][1]; r.z = o[i][2]; r.w = o[i][3];
-                    if (vbi != 0xffffu) {  // border cells rejected by the f64 bounds test (rare) -- and, under ALIGNZ, bytes outside the row
+                    if (vbi != 0xffffu) {  // border cells rejected by the f64 bounds test (rare)
                         u32 mw[4];
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
@@ -510,54 +490,6 @@ __global__ __launch_bounds__(256, ROT90_WAVES) void k_rot90(const u8* __restrict
                         }
                         r.x &= mw[0]; r.y &= mw[1]; r.z &= mw[2]; r.w &= mw[3];
                     }
-                }
-                if (RGBOUT) {
-                    const u8* px = rgb_hw3 + (y * W + (act ? x : 0)) * 3;
-                    const u32 R = px[0], G = px[1], B = px[2];
-                    const u32 C0 = R | (G << 8) | (B << 16) | (R << 24), C1 = G | (B << 8) | (R << 16) | (G << 24), C2 = B | (R << 8) | (G << 16) | (B << 24);
-                    const u32 oc[4] = {r.x, r.y, r.z, r.w};
-                    u32 w[12];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        // carved == 1 (the chain only ever holds 0 / 1): bytes 0x00 / 0xff, spread over the voxel's three colour bytes
-                        u32 e = oc[q] ^ 0x01010101u;                                   // 0 where the byte is 1
-                        e = ~(((e & 0x7f7f7f7fu) + 0x7f7f7f7fu) | e) & 0x80808080u;   // 0x80 where that byte is zero
-                        e = (e >> 7) * 0xffu;
-                        w[3 * q] = perm(e, e, 0x01000000u) & C0; w[3 * q + 1] = perm(e, e, 0x02020101u) & C1; w[3 * q + 2] = perm(e, e, 0x03030302u) & C2;
-                    }
-                    // A lane's 48 bytes go through a wave-private LDS window and leave in ADDRESS order: the 8 lanes of a row segment hold
-                    // 384 contiguous bytes (three whole lines), so chunk c = 64 k + lane of the wave's 3 KiB belongs to lane c / 3 and every
-                    // store instruction writes whole lines (three stores of 16 bytes every 48 touched each line three times: 1.05 ms).
-                    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { u32x4 v; v.x = w[4 * k]; v.y = w[4 * k + 1]; v.z = w[4 * k + 2]; v.w = w[4 * k + 3]; xch[wv * 192 + 3 * lane + k] = v; }
-                    const i64 mybase = act ? 3 * ((x * H + y) * D + zo) : -1;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int c = 64 * k + lane, L = c / 3, part = c - 3 * L;
-                        const u32x4 v = xch[wv * 192 + c];
-                        const i64 lb = __shfl((long long)mybase, L);
-                        if (lb >= 0) *(u32x4*)(out + lb + 16 * part) = v;
-                    }
-                    continue;
-                }
-                if (ALIGNZ) {
-                    u8* opa = out + (x * H + y) * D + zlo;                 // 16-byte aligned by construction
-                    if (zlo >= 0 && zlo + 15 < D) __builtin_nontemporal_store(r, (u32x4*)opa);
-                    else {                                                 // one of the two clipped pieces of the row: its own bytes only --
-                        const u32 t4[4] = {r.x, r.y, r.z, r.w};            // whole dwords inside the row as dwords, the rest byte by byte
-                        const int b0 = zlo < 0 ? (int)-zlo : 0, b1 = zlo + 16 > D ? (int)(D - zlo) : 16;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            if (4 * w >= b0 && 4 * w + 4 <= b1) *(u32*)(opa + 4 * w) = t4[w];
-                            else if (4 * w + 4 > b0 && 4 * w < b1) {
-#pragma unroll
-                                for (int b = 0; b < 4; ++b)
-                                    if (4 * w + b >= b0 && 4 * w + b < b1) opa[4 * w + b] = (u8)(t4[w] >> (8 * b));
-                            }
-                        }
-                    }
-                    continue;
                 }
                 u8* op = out + (x * H + y) * D + zo;
                 if (!RAGGED || zo + 15 < D) __builtin_nontemporal_store(r, (u32x4_u*)op);
@@ -1546,24 +1478,22 @@ int pb3d_perm_valid_table(pb3d_ctx* ctx, const double M[9], const double off[3],
 }
 
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
-                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out, const u8* d_rgb_hw3) {
+                            const u8* d_mask_src, const u8* d_mask_dst, u8* d_out) {
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     const PermMap pm = perm_map(M, off);
     const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
     PB3D_REQUIRE(rot90 || (D % 4 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 3u) == 0), "pb3d_rotate_perm: needs D %% 4 == 0");
-    PB3D_REQUIRE(!d_rgb_hw3 || (rot90 && W <= 65535 * 128 && H <= 65535), "pb3d_rotate_perm: colour output is a 90-degree step");
     if (rot90 && W <= 65535 * 128 && H <= 65535) {
         u32* bits; int nw;
         PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-        // rows that are not whole lines, but all rows of a plane at one phase: the plane-shifted tile grid (k_rot90<.., ALIGNZ>)
-        // ... or, better, the stream of each x-row tiled in whole lines (k_rot90_flat); tune misc2: 2 = neither, 3 = the plane-shifted grid
-        const bool lines_ok = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
-        // (round 3) the flat form also takes streams that are whole 16-byte pieces but not whole lines (H * D % 16 == 0, e.g. 500 x 400 x 500):
-        // the last segment of an x-row's stream is ragged, and the rows of odd x start mid-line (their stores are aligned pieces, not lines)
-        const bool flat16 = !d_rgb_hw3 && D % 128 != 0 && (H * D) % 16 == 0 && D >= 128 && ctx->tune_misc[2] != 2 && ctx->tune_misc[2] != 4;
-        const bool flat = (lines_ok || flat16) && ctx->tune_misc[2] != 3 && H * D < (1ll << 31) - 256 && (((uintptr_t)d_out) & 127u) == 0;
-        const bool alignz = lines_ok && !flat;
-        const i64 nzt = alignz ? (D + 127 + 127) / 128 : (D + 127) / 128;
+        // rows that are not whole lines: the stream of each x-row tiled in whole lines (k_rot90_flat / k_rot90wf) -- streams that are whole lines
+        // (H * D % 128 == 0: every real shape of the reference whose longer mask side is the height) or at least whole 16-byte pieces
+        // (H * D % 16 == 0, e.g. 500 x 400 x 500: the last segment of an x-row's stream is ragged, the rows of odd x start mid-line);
+        // tune misc2: 2 = the row-wise tile kernel instead, 4 = whole-line streams only
+        const bool lines_ok = D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
+        const bool flat16 = D % 128 != 0 && (H * D) % 16 == 0 && D >= 128 && ctx->tune_misc[2] != 2 && ctx->tune_misc[2] != 4;
+        const bool flat = (lines_ok || flat16) && H * D < (1ll << 31) - 256 && (((uintptr_t)d_out) & 127u) == 0;
+        const i64 nzt = (D + 127) / 128;
         const i64 tiles = nzt * ((W + 127) / 128);
         const int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_misc[1]);
         const TileMap tm = {(int)nzt, (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2] == 1 ? 1 : 0};
@@ -1571,11 +1501,7 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
 #ifndef PB3D_ROT90_DEPTH
 #define PB3D_ROT90_DEPTH 1
 #endif
-        if (d_rgb_hw3) {
-            PB3D_REQUIRE(D % 16 == 0 && pm.c2 % 16 == 0 && (((uintptr_t)d_out) & 15u) == 0, "pb3d_rotate_perm: colour output needs D %% 16 == 0");
-            hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
-                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm, d_rgb_hw3);
-        } else if (flat && W >= 160 && H * D < (1ll << 31) - 1024 && W * H < 0xffffffffll && ctx->tune_rot90_wide != 2) {
+        if (flat && W >= 160 && H * D < (1ll << 31) - 1024 && W * H < 0xffffffffll && ctx->tune_rot90_wide != 2) {
             // 256-byte segments, 1024 threads (tune rot90_wide = 2: the 128-row x 128-byte form below)
             if (!ctx->rot90wf_lds_set) {
                 PB3D_HIP(hipFuncSetAttribute((const void*)k_rot90wf, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256 + 48 * 1024));
@@ -1602,10 +1528,7 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
             const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
             hipLaunchKernelGGL(k_rot90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
                                pm.c0, pm.c2, W, H, D, TS, fm, pb3d_make_magic((u32)D), nseg);
-        } else if (alignz)
-            hipLaunchKernelGGL((k_rot90<PB3D_ROT90_DEPTH, true, false, true>), grid, dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
-                               (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TY, tm);
-        else if (D % 16 == 0 && pm.c2 % 16 == 0 && W >= 256 && D >= 256 && ctx->tune_rot90_wide != 2 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0) {
+        } else if (D % 16 == 0 && pm.c2 % 16 == 0 && W >= 256 && D >= 256 && ctx->tune_rot90_wide != 2 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0) {
             // the 256 x 256-tile form (tune rot90_wide = 2: the 128-tile kernel).  Measured with tools/tybench.py on one box, variants
             // interleaved (ms, 128-tile kernel -> this one): 1024^3 0.464 -> 0.430, 512^3 0.0665 -> 0.0608, 512 x 278 x 512 0.046 -> 0.035.
             // Workgroups per CU: as many (up to 8) as leave a workgroup at least 4 planes.  With the mask flags in LDS (tools/tybench.py,

@@ -574,13 +574,21 @@ static bool step_fits(const double M[9]) {
 // is not 0/1): nothing was written and the caller runs the byte chain.  known_binary = 0 costs one host wait for the slice kernel.
 // d_occ == NULL: the source is the all-ones grid of global_carve (nothing is read).  d_rgb_hw3 != NULL: d_out is the (W,H,D,3)
 // colour volume of global_carve (reference :289), written by the un-slicing pass.
+// Mx / offx != NULL: ONE rotation step with this matrix and offset (pb3d_rotate_carve_dev), no 0-degree carve in front of it.
 static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const u8* d_mask_wh, int angle_interval, u8* d_out, const u8* d_rgb_hw3,
-                     int known_binary, int* took) {
+                     int known_binary, int* took, const double* Mx = nullptr, const double* offx = nullptr) {
     *took = 0;
-    const int nsteps = 90 / angle_interval + 1;
-    const int nrot = nsteps - 1;
-    // (a pinned byte-tile kernel -- the parity tests pin each of them in turn -- means the byte chain)
-    if (ctx->tune_sliced == 1 || ctx->tune_rotate_tile != 0 || nrot < (ctx->tune_sliced == 2 ? 1 : 2)) return PB3D_OK;
+    const int nrot = Mx ? 1 : 90 / angle_interval;
+    // (tune sliced = 1: the byte chain with the arithmetic kernel -- the pinned reference of the parity tests)
+    if (ctx->tune_sliced == 1 || nrot < 1) return PB3D_OK;
+    if (!Mx && nrot == 1 && angle_interval == 90) {
+        // a single 90-degree step: the permutation kernels of csrc/rotate_tiled.hip move it at 2 B/voxel (when W + D is even)
+        const i64 sh[3] = {W, H, D};
+        double M[9], off[3];
+        PB3D_TRY(pb3d_rotinv(90, M));
+        PB3D_TRY(pb3d_offset(M, sh, off));
+        if (pb3d_is_perm_step(M, off, W, D)) return PB3D_OK;
+    }
     const i64 Dp = (D + 15) & ~(i64)15;
     const int G = (int)((H + 31) / 32);
     const i64 nzb = Dp / 16;
@@ -598,13 +606,18 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
     int rc = pb3d_dev_alloc(ctx, sbytes, &B);
     if (rc != PB3D_OK) { (void)pb3d_dev_free(ctx, A); return rc; }
     auto body = [&]() -> int {
-        hipLaunchKernelGGL(k_s32_maskbits, dim3((unsigned)(((i64)G * W + 255) / 256)), dim3(256), 0, ctx->stream, d_mask_wh, W, H, G, (u32*)mb, flag);
+        if (d_mask_wh) {
+            hipLaunchKernelGGL(k_s32_maskbits, dim3((unsigned)(((i64)G * W + 255) / 256)), dim3(256), 0, ctx->stream, d_mask_wh, W, H, G, (u32*)mb, flag);
+        } else {        // no mask: every plane bit passes (bits of planes past H stay zero in the volume: the slice pass never sets them)
+            PB3D_HIP(hipMemsetAsync(mb, 0xff, (size_t)G * W * sizeof(u32), ctx->stream));
+            PB3D_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+        }
         const u32 total = (u32)((i64)G * W * nzb);
         const pb3d_magic mzb = pb3d_make_magic((u32)nzb), mw = pb3d_make_magic((u32)W), mg = pb3d_make_magic((u32)G);
         const int gfast = ctx->tune_s32_order == 1;       // (measured: the order of the wavefronts makes no difference, 0.61 ms either way at 1024^3 / 45)
         if (d_occ) {
             const bool nt = W * H * D >= (i64)256 << 20;
-#define PB3D_SLICE(WH, NTL) hipLaunchKernelGGL((k_s32_slice<WH, NTL>), dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, (const u32*)mb, W, H, D, Dp, mzb, mw, total, flag, mg, gfast)
+#define PB3D_SLICE(WH, NTL) hipLaunchKernelGGL((k_s32_slice<WH, NTL>), dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, d_occ, (u32*)A, Mx ? (const u32*)nullptr : (const u32*)mb, W, H, D, Dp, mzb, mw, total, flag, mg, gfast)
             if (D % 16 == 0) { if (nt) PB3D_SLICE(true, true); else PB3D_SLICE(true, false); }
             else { if (nt) PB3D_SLICE(false, true); else PB3D_SLICE(false, false); }
 #undef PB3D_SLICE
@@ -630,7 +643,7 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
         int nrot_tab = nrot;
         u32* vbits = nullptr;
         int vnw = 0, pc0 = 0, pc2 = 0;
-        if (nrot * angle_interval == 90 && ctx->tune_s32_fuse_last != 1 && H <= 65535ll * 32) {
+        if (!Mx && nrot * angle_interval == 90 && ctx->tune_s32_fuse_last != 1 && H <= 65535ll * 32) {
             double M[9], off[3];
             PB3D_TRY(pb3d_rotinv(90, M));
             PB3D_TRY(pb3d_offset(M, shape, off));
@@ -645,9 +658,12 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
             memset(&sp, 0, sizeof(sp));
             for (int k = 0; k < ns; ++k) {
                 double M[9], off[3];
-                PB3D_TRY(pb3d_rotinv((s0 + k + 1) * angle_interval, M));
-                PB3D_TRY(pb3d_offset(M, shape, off));
-                if (!step_fits(M)) return PB3D_EUNSUPPORTED;            // (never: every Rinv is a rotation)
+                if (Mx) { memcpy(M, Mx, sizeof(M)); memcpy(off, offx, sizeof(off)); }
+                else {
+                    PB3D_TRY(pb3d_rotinv((s0 + k + 1) * angle_interval, M));
+                    PB3D_TRY(pb3d_offset(M, shape, off));
+                }
+                if (!step_fits(M)) return PB3D_EUNSUPPORTED;            // (every Rinv is a rotation; a caller's own matrix may not be)
                 sp.p[k] = RotParams{M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
             }
             // the tile programs of this run of steps: where an earlier call left them, or built now
@@ -715,4 +731,10 @@ int pb3d_process_grid_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D
 int pb3d_global_carve_sliced(pb3d_ctx* ctx, const u8* d_mask_wh, const u8* d_rgb_hw3, i64 W, i64 H, i64 D, int angle_interval, u8* d_out_rgb,
                              int* took) {
     return s32_chain(ctx, nullptr, W, H, D, d_mask_wh, angle_interval, d_out_rgb, d_rgb_hw3, 1, took);
+}
+
+// one rotation step with the caller's matrix (pb3d_rotate_carve_dev) on 0/1 data; *took = 0: not applicable (data, shape, matrix)
+int pb3d_rotate_step_sliced(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const double M[9], const double off[3], const u8* d_mask_wh, u8* d_out,
+                            int* took) {
+    return s32_chain(ctx, d_occ, W, H, D, d_mask_wh, 90, d_out, nullptr, 0, took, M, off);
 }

@@ -688,33 +688,28 @@ def test_sharded_projection_keys(pb3d_gpu, oracle):
         dist.comm_destroy()
 
 
-def test_generic_angle_tiled_kernel_large(pb3d_gpu, oracle):
-    """grids above 2^21 voxels take the LDS-tiled lookup-table kernel for generic angles; 0/1 data stays on the table
-    path, 0..255 data must raise the device flag and be redone by the arithmetic kernel -- both bit-exact."""
+def test_generic_angle_steps_large(pb3d_gpu, oracle):
+    """generic-angle steps on larger grids: 0/1 data runs bit-sliced (csrc/sliced.hip; since round 4 also a SINGLE step, angle step 50),
+    0..255 data -- or one voxel with a value > 1 -- must raise the slice pass's flag and be redone by the arithmetic kernel; both forms
+    (and the pinned byte chain, tune sliced = 1) bit-exact.  Shapes: rows at arbitrary byte alignment, ragged row ends, fewer than 32
+    planes, D % 16 == 0 but D % 32 != 0, two x-tiles."""
     rng = np.random.default_rng(43)
-    # (160,90,160) / (176,64,192): 32-plane bit-sliced kernel (ragged / whole passes); (200,60,180) / (131,128,130) /
-    # (133,121,129): the same kernel with rows at arbitrary byte alignment and ragged row ends; (400,20,272) / (300,20,357):
-    # fewer than 32 planes -> 8-plane kernel, aligned and byte-wise forms
-    # (271,33,240): D % 16 == 0 but D % 32 != 0 -- the wide kernel's 32-voxel runs straddle the row end (found by tools/fuzz_gpu.py)
-    # (355,16,355) / (290,40,333): odd rows through the packed kernel's byte-aligned form (two x-tiles, edge slots skipped, last runs partial)
     for (W, H, D) in [(160, 90, 160), (176, 64, 192), (400, 20, 272), (200, 60, 180), (131, 128, 130), (133, 121, 129), (300, 20, 357),
                       (271, 33, 240), (355, 16, 355), (290, 40, 333)]:
         m = rng.random((H, W)) < 0.9
         g_bin = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         g_full = rng.integers(0, 256, (W, H, D), dtype=np.uint8)
-        g_one_big = g_bin.copy(); g_one_big[W // 2, H // 2, D // 2] = 200      # a single value > 1 must switch the whole step
+        g_one_big = g_bin.copy(); g_one_big[W // 2, H // 2, D // 2] = 200      # a single value > 1 must switch the whole call
         for ai in (45, 30, 50):
             for g in (g_bin, g_full, g_one_big):
                 want = oracle.process_voxel_grid(g, m, ai)
-                # the 64x64 / 32-plane, the 128x128 / 16-plane and the packed 256x256 / 8-plane kernels (any D: rows that are not
-                # multiples of 16 bytes take its byte-aligned form); the library picks by size
-                for tile in (64, 128, 256):
-                    pb3d_gpu._lib.set_tuning("rotate_tile", tile)
+                for sliced in (0, 1):
+                    pb3d_gpu._lib.set_tuning("sliced", sliced)
                     try:
                         got = pb3d_gpu.process_voxel_grid(g, m, ai)
                     finally:
-                        pb3d_gpu._lib.set_tuning("rotate_tile", 0)
-                    assert np.array_equal(got, want), (W, H, D, ai, tile, int((got != want).sum()))
+                        pb3d_gpu._lib.set_tuning("sliced", 0)
+                    assert np.array_equal(got, want), (W, H, D, ai, sliced, int((got != want).sum()))
 
 
 def test_sliced_chain_equals_byte_chain_equals_oracle(pb3d_gpu, oracle):
@@ -741,42 +736,61 @@ def test_sliced_chain_equals_byte_chain_equals_oracle(pb3d_gpu, oracle):
                     finally:
                         pb3d_gpu._lib.set_tuning("sliced", 0)
                     assert np.array_equal(got, want), (W, H, D, ai, kind, sliced, int((got != want).sum()))
-    # one rotation step through the sliced kernels (forced): 90 degrees (even and odd W + D), 60 degrees
+    # one rotation step: 60 degrees and 90 degrees with W + D odd run through the sliced kernels, 90 degrees with W + D even on the
+    # permutation kernels; rotate_carve with the caller's own matrix (no 0-degree carve in front, with and without a mask)
+    import ctypes as C
+    from pb3d import device as dev
+    L = pb3d_gpu._lib
     for (W, H, D) in [(64, 40, 64), (37, 11, 38), (130, 70, 131), (128, 33, 128)]:
         g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         m = rng.random((H, W)) < 0.9
         for ai in (90, 60):
             want = oracle.process_voxel_grid(g, m, ai)
-            pb3d_gpu._lib.set_tuning("sliced", 2)
-            try:
-                got = pb3d_gpu.process_voxel_grid(g, m, ai)
-            finally:
-                pb3d_gpu._lib.set_tuning("sliced", 0)
-            assert np.array_equal(got, want), (W, H, D, ai, int((got != want).sum()))
+            for sliced in (0, 1):
+                L.set_tuning("sliced", sliced)
+                try:
+                    got = pb3d_gpu.process_voxel_grid(g, m, ai)
+                finally:
+                    L.set_tuning("sliced", 0)
+                assert np.array_equal(got, want), (W, H, D, ai, sliced, int((got != want).sum()))
+        d_g = dev.from_numpy(g); d_m = dev.from_numpy(np.ascontiguousarray(m.T).astype(np.uint8)); d_o = dev.DeviceBuffer(g.size)
+        for ang in (33, 60, 90):
+            M = pb3d_gpu.voxel_carving_utils._rotation_matrix_inv(ang)
+            off = np.zeros(3); shape = (C.c_int64 * 3)(W, H, D)
+            L.check(L.load().pb3d_offset(L.p_dbl(M), shape, L.p_dbl(off)))
+            res = {}
+            for masked in (True, False):
+                for sliced in (0, 1):
+                    L.set_tuning("sliced", sliced)
+                    try:
+                        dev.rotate_carve(d_g, W, H, D, M, off, d_m if masked else None, d_o)
+                        res[(masked, sliced)] = d_o.download((W, H, D))
+                    finally:
+                        L.set_tuning("sliced", 0)
+                assert np.array_equal(res[(masked, 0)], res[(masked, 1)]), (W, H, D, ang, masked)
+            assert np.array_equal(res[(True, 0)], oracle.carve_voxel_grid_with_masks(res[(False, 0)], m)), (W, H, D, ang)
+        for b in (d_g, d_m, d_o):
+            b.free()
 
 
-def test_packed_kernel_odd_rows_with_dirty_slack(pb3d_gpu, oracle):
-    """rows that are not multiples of 16 bytes: the packed generic-angle kernel reads whole 16-byte units, the last one of the volume up
-    to 15 bytes into the allocation's slack.  Whatever lies there (here: 0xff) must neither change a voxel nor send the step to the
-    arithmetic fallback by tripping the 'value > 1' check; same for a volume that ends exactly where its allocation does."""
+def test_odd_rows_with_dirty_slack(pb3d_gpu, oracle):
+    """rows that are not multiples of 16 bytes: the slice pass reads 16-byte pieces at whatever alignment the rows have and the last piece of
+    a row byte-wise -- whatever lies behind the volume in its allocation (here: 0xff) must neither change a voxel nor trip the 'value > 1'
+    check."""
     from pb3d import device as dev
     rng = np.random.default_rng(8)
     for (W, H, D) in [(300, 16, 357), (355, 9, 355), (271, 40, 333)]:
         g = (rng.random((W, H, D)) < 0.5).astype(np.uint8)
         m = rng.random((H, W)) < 0.9
-        want = oracle.process_voxel_grid(g, m, 45)
         n = g.size
         dirty = np.full(n + 64, 0xff, np.uint8); dirty[:n] = g.ravel()
         d_in = dev.from_numpy(dirty); d_m = dev.from_numpy(np.ascontiguousarray(m.T).astype(np.uint8))
         d_o = dev.DeviceBuffer(n); d_t = dev.DeviceBuffer(n)
-        for tile in (0, 256):
-            pb3d_gpu._lib.set_tuning("rotate_tile", tile)
-            try:
-                dev.process_grid(d_in, W, H, D, d_m, 45, d_o, d_t)
-                got = d_o.download((W, H, D))
-            finally:
-                pb3d_gpu._lib.set_tuning("rotate_tile", 0)
-            assert np.array_equal(got, want), (W, H, D, tile, int((got != want).sum()))
+        for ai in (45, 60):
+            want = oracle.process_voxel_grid(g, m, ai)
+            dev.process_grid(d_in, W, H, D, d_m, ai, d_o, d_t)
+            got = d_o.download((W, H, D))
+            assert np.array_equal(got, want), (W, H, D, ai, int((got != want).sum()))
         for b in (d_in, d_m, d_o, d_t):
             b.free()
 
@@ -911,10 +925,10 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
 
 @pytest.mark.gpu
 def test_full_size_process_grid_45_against_oracle_slab(pb3d_gpu, oracle):
-    """process_voxel_grid(occ, binary, 45) on the 1024^3 synthetic grid, device resident (0-degree carve, two generic-angle
-    steps through the wide-tile bit-sliced kernel, the 90-degree step through k_rot90).  A rotation about Y never mixes
-    Y-planes, so a slab of planes of the full result must equal the oracle run on that slab alone; and the two generic-angle
-    tile kernels (64 x 64 / 32 planes, 128 x 128 / 16 planes), written independently, must agree on the whole volume."""
+    """process_voxel_grid(occ, binary, 45) on the 1024^3 synthetic grid, device resident (the bit-sliced chain: slice with the 0-degree
+    carve folded in, the 45-degree table step, the 90-degree step un-slicing in its own stores).  A rotation about Y never mixes
+    Y-planes, so a slab of planes of the full result must equal the oracle run on that slab alone; and the byte chain (arithmetic
+    kernel + permutation kernel), written independently, must agree on the whole volume."""
     import synth_host
     from pb3d import device as dev
     S = int(os.environ.get("PB3D_TEST_FULL_SIZE", "1024"))
@@ -925,17 +939,16 @@ def test_full_size_process_grid_45_against_oracle_slab(pb3d_gpu, oracle):
     dev.synth_mask16(S, d_binary_wh=d_mwh)
     lab, binary, rgb = synth_host.mask16(S)                  # (H,W) images
     dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out, d_tmp)
-    full = None
-    for tile in (64, 128):                                   # the default at this size is the packed 256-tile kernel
-        pb3d_gpu._lib.set_tuning("rotate_tile", tile)
-        try:
-            dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out64, d_tmp)
-        finally:
-            pb3d_gpu._lib.set_tuning("rotate_tile", 0)
-        dev.sync()
-        if full is None:
-            full = d_out.download((S, S, S))
-        assert np.array_equal(full, d_out64.download((S, S, S))), tile
+    # the byte chain (0-degree carve folded into the arithmetic kernel's 45-degree step, the 90-degree step on the permutation kernel),
+    # written independently of the bit-sliced chain, must agree on the whole volume
+    pb3d_gpu._lib.set_tuning("sliced", 1)
+    try:
+        dev.process_grid(d_occ, S, S, S, d_mwh, 45, d_out64, d_tmp)
+    finally:
+        pb3d_gpu._lib.set_tuning("sliced", 0)
+    dev.sync()
+    full = d_out.download((S, S, S))
+    assert np.array_equal(full, d_out64.download((S, S, S)))
     assert full.max() <= 1 and 0 < int(full.sum()) < nvox
     occ = d_occ.download((S, S, S))
     for y0 in (0, S // 2 - 1, S - 3):

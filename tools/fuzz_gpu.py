@@ -41,10 +41,10 @@ def main():
         m = rng.random((H, W)) < rng.uniform(0.2, 1.0)
         info = (n, W, H, D, ai)
         want = oracle.process_voxel_grid(g, m, ai)
-        for tile in (64, 128, 256, 0):
-            pb3d._lib.set_tuning("rotate_tile", tile)
-            ok("process", pb3d.process_voxel_grid(g, m, ai), want, info + (tile,))
-        pb3d._lib.set_tuning("rotate_tile", 0)
+        for sliced in (0, 1):        # the bit-sliced path and the byte chain (arithmetic kernel + permutation kernels)
+            pb3d._lib.set_tuning("sliced", sliced)
+            ok("process", pb3d.process_voxel_grid(g, m, ai), want, info + (sliced,))
+        pb3d._lib.set_tuning("sliced", 0)
         if n % 4 == 1 and W * H * D <= 300000:       # the same loop on a grid of another dtype (csrc/rotate_typed.hip), bytes and dtype compared
             dt = str(rng.choice(["bool", "int8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64", "complex64", "complex128"]))
             if dt == "bool": gt = rng.random((W, H, D)) < dens
