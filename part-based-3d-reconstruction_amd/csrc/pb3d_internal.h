@@ -41,6 +41,7 @@ struct pb3d_ctx {
     int tune_ccl_blocks;        // knob "ccl_blocks": workgroups per CU of the labelling's last pass (0 = default)
     int tune_ccl_init_blocks;   // knob "ccl_init_blocks": workgroups per CU of the labelling's first pass (0 = 16)
     int tune_ccl_tilecols;      // knob "ccl_tilecols": windows per level of a plane-to-plane merge tile (0 = 32)
+    int tune_points_fill;       // knob "points_fill": 1 = the block form of the two-pass fill (k_points_fill16; development A/B)
     int tune_ccl_merge;         // knob "ccl_merge": 0 = tile kernels where the rows fit, 1 = always the pairwise kernel (development A/B)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).

@@ -516,6 +516,188 @@ __global__ __launch_bounds__(256) void k_points_fill16(const u8* __restrict__ gr
     if (threadIdx.x < nbytes - tail0) co[tail0 + threadIdx.x] = stream_byte(tail0 + threadIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fill pass of the two-pass protocol, WAVE-PRIVATE form (round 4).  k_points_fill16 above ranks, stages and writes per BLOCK:
+// rank -> LDS -> coordinates of 512 points at a time -> colours, five block barriers and 31 KB of LDS (five blocks per CU), and the
+// SQ counters of round 2 / the 4-bit colour-id experiment of round 3 showed the pass bound by that chain, not by its bytes.
+// Here every wavefront is on its own: it owns 1024 consecutive voxels (a quarter of a count-pass block), finds its output offset
+// from the block's scanned offset + the popcounts of the earlier waves' masks, and walks its voxels in four rounds of 256 -- lane l
+// takes voxels 4 l .. 4 l + 3 of the round, so a round's points are contiguous in the output and every lane takes part in every
+// step.  Per round: rank inside the wave (one shuffle scan), coordinates from the lane's first voxel (one pair of exact
+// multiply-high divisions per LANE and round, then increments), the points' floats scattered into a wave-private LDS window at the
+// phase of the output address, whole 16-byte pieces stored (1 KB contiguous per instruction), the last partial piece carried into
+// the next round; the colours likewise as 24-bit records strung into aligned dwords, four records = three dwords at a time.
+// No block barrier, 4.2 KB of LDS per wave.  All four rounds' loads (12 bytes per lane where something is selected) are in flight
+// before the first is used.
+// ------------------------------------------------------------------------------------------------
+typedef u32 u32x3v_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_points_fillw(const u8* __restrict__ grid, SelParams p, const i64* __restrict__ block_off,
+                                                      float* __restrict__ pts, u8* __restrict__ cols, const unsigned short* __restrict__ masks) {
+    constexpr int FW = 4 + 3 * 256 + 4;                  // floats: <= 3 carried + 768 of a round
+    constexpr int RW = 8 + 256 + 8;                      // records: <= 8 waiting + 256 of a round + the over-read of the last group
+    __shared__ __attribute__((aligned(16))) float fwin[4][FW];
+    __shared__ __attribute__((aligned(16))) u32 rwin[4][RW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 bid = blockIdx.x;
+    const i64 wbase = (i64)bid * kBlockVox + 1024 * wv;
+    if (wbase >= p.nlat) return;                          // (whole wave; the kernel has no block barrier)
+    const unsigned short* bm = masks + (i64)bid * 256;
+    const u32 mymask = bm[64 * wv + lane];                // selection of voxels wbase + 16 lane .. + 15 (bits past the grid's end are zero)
+    u32 pre = 0;
+    for (int q = 0; q < wv; ++q) pre += (u32)__popc((u32)bm[64 * q + lane]);
+    u32 tot = (u32)__popc(mymask);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); tot += __shfl_xor(tot, o); }
+    if (tot == 0) return;
+    const i64 out0 = block_off[bid] + pre;
+    float* fw = fwin[wv];
+    u32* rw = rwin[wv];
+    // ---- all loads of the wave
+    u32 sel[4];
+    u32 w[4][C == 3 ? 3 : 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const u32 m = (u32)__shfl((int)mymask, 16 * r + (lane >> 2));
+        sel[r] = (m >> (4 * (lane & 3))) & 0xfu;
+#pragma unroll
+        for (int k = 0; k < (C == 3 ? 3 : 1); ++k) w[r][k] = 0u;
+        if (sel[r]) {
+            const i64 v = wbase + 256 * r + 4 * lane;
+            if (v + 4 <= p.nlat) {
+                if (C == 3) { const u32x3v_a4 t = *(const u32x3v_a4*)(grid + 3 * v); w[r][0] = t.x; w[r][1] = t.y; w[r][2] = t.z; }
+                else w[r][0] = *(const u32*)(grid + v);
+            } else {                                      // the grid's ragged end
+                for (int b = 0; b < 4 * (C == 3 ? 3 : 1); ++b)
+                    if (C * v + b < C * p.nlat) w[r][b >> 2] |= (u32)grid[C * v + b] << (8 * (b & 3));
+            }
+        }
+    }
+    // ---- the wave's first voxel -> (b0, b1, b2)   (nlat < 2^32: the launcher's condition)
+    u32 b0, b1, b2;
+    {
+        const u32 rr = magic_div((u32)wbase, p.m2, p.s2a, p.s2b);
+        b2 = (u32)wbase - rr * (u32)p.A2;
+        const u32 q = magic_div(rr, p.m1, p.s1a, p.s1b);
+        b1 = rr - q * (u32)p.A1; b0 = q;
+    }
+    // ---- output streams
+    float* gout = pts + 3 * out0;
+    const u32 shift = (u32)(((uintptr_t)gout >> 2) & 3u);           // floats past a 16-byte boundary
+    float* gal = gout - shift;                                      // aligned; fw[i] <-> gal[i]
+    u32 pend = shift, first_lo = shift;                             // floats [0, first_lo) of the first piece belong to the wave before
+    u8* co = cols + (i64)C * out0;
+    const u32 nbytes = (u32)C * tot;
+    const u32 head = (u32)((4 - ((uintptr_t)co & 3u)) & 3u);
+    const u32 hb = head < nbytes ? head : nbytes;                   // bytes up to the first dword boundary of the colour stream
+    u32* cw = (u32*)(co + hb);
+    // records: record k of the wave sits at window index k + roff until the first compaction; groups start at multiples of 4
+    const u32 r00 = C == 3 ? hb / 3 : hb, ph = C == 3 ? hb - 3 * r00 : 0u;      // first record / byte phase of the aligned dwords
+    const u32 roff = (4u - r00) & 3u;
+    u32 rfill = roff, gidx = r00 ? 4u : 0u, gdone = 0;
+    bool head_done = hb == 0;
+    auto emit_head = [&]() {
+        if ((u32)lane < hb) co[lane] = C == 3 ? (u8)(rw[roff] >> (8 * lane)) : (u8)rw[roff + lane];
+        head_done = true;
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const u32 c = (u32)__popc(sel[r]);
+        u32 inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        const u32 n = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        if (n == 0) continue;
+        // ---- scatter: coordinates and colour records of this lane's selected voxels
+        {
+            const u32 x = b2 + 256u * r + 4u * lane;                 // < A2 + 1024
+            const u32 q2 = magic_div(x, p.m2, p.s2a, p.s2b);
+            u32 a2 = x - q2 * (u32)p.A2;
+            const u32 y = b1 + q2;
+            const u32 q1 = magic_div(y, p.m1, p.s1a, p.s1b);
+            u32 a1 = y - q1 * (u32)p.A1;
+            u32 a0 = b0 + q1;
+            u32 k = inc - c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((sel[r] >> i) & 1u) {
+                    float* l = fw + pend + 3 * k;
+                    l[0] = (float)a2; l[1] = (float)a1; l[2] = (float)a0;
+                    u32 rec;
+                    if (C == 3) {
+                        const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+                        rec = __builtin_amdgcn_alignbyte(j + 1 < 3 ? w[r][j + 1 < 3 ? j + 1 : 0] : 0u, w[r][j], (u32)sh) & 0x00ffffffu;
+                    } else rec = (w[r][0] >> (8 * i)) & 0xffu;
+                    rw[rfill + k] = rec;
+                    ++k;
+                }
+                if (++a2 == (u32)p.A2) { a2 = 0; if (++a1 == (u32)p.A1) { a1 = 0; ++a0; } }
+            }
+        }
+        wave_sync();
+        // ---- points: whole 16-byte pieces leave, the rest is carried
+        {
+            const u32 nfl = pend + 3 * n, npc = nfl >> 2, left = nfl & 3u;
+            for (u32 pz = lane; pz < npc; pz += 64) {
+                if (pz == 0 && first_lo) { for (u32 f = first_lo; f < 4; ++f) gal[f] = fw[f]; }
+                else *(f32x4w*)(gal + 4 * pz) = *(const f32x4w*)(fw + 4 * pz);      // (nontemporal stores measured slower here: fill 1.47 -> 1.62 ms at 1024^3)
+            }
+            if (npc) {
+                first_lo = 0;
+                float t = 0.f;
+                if ((u32)lane < left) t = fw[4 * npc + lane];
+                wave_sync();
+                if ((u32)lane < left) fw[lane] = t;
+                gal += 4 * npc; pend = left;
+            } else pend = nfl;
+        }
+        // ---- colours: groups of four records = C dwords whose records (C == 3: and the one behind them) have arrived
+        {
+            rfill += n;
+            const u32 need = C == 3 ? 1u : 0u;
+            const u32 ng = rfill >= gidx + need ? (rfill - gidx - need) >> 2 : 0u;
+            if (ng) {
+                if (!head_done) emit_head();
+                for (u32 g = lane; g < ng; g += 64) {
+                    const u32x4v va = *(const u32x4v*)(rw + gidx + 4 * g);
+                    if (C == 3) {
+                        const u32 e4 = rw[gidx + 4 * g + 4];
+                        const u32 W0 = va.x | (va.y << 24), W1 = (va.y >> 8) | (va.z << 16), W2 = (va.z >> 16) | (va.w << 8), W3 = e4;
+                        u32* d = cw + 3 * (gdone + g);
+                        d[0] = __builtin_amdgcn_alignbyte(W1, W0, ph); d[1] = __builtin_amdgcn_alignbyte(W2, W1, ph);
+                        d[2] = __builtin_amdgcn_alignbyte(W3, W2, ph);
+                    } else cw[gdone + g] = va.x | (va.y << 8) | (va.z << 16) | (va.w << 24);
+                }
+                const u32 src = gidx + 4 * ng, rem = rfill - src;      // <= 4 records wait for the next round
+                u32 t = 0;
+                if ((u32)lane < rem) t = rw[src + lane];
+                wave_sync();
+                if ((u32)lane < rem) rw[lane] = t;
+                gdone += ng; gidx = 0; rfill = rem;
+            }
+        }
+        wave_sync();
+    }
+    // ---- the ends of the two streams
+    if ((u32)lane >= first_lo && (u32)lane < pend) gal[lane] = fw[lane];
+    if (!head_done) emit_head();
+    {
+        const u32 q0 = hb + 4 * (u32)C * gdone;               // first stream byte that has not left
+        if (q0 < nbytes && (u32)lane < nbytes - q0) {
+            if (C == 3) { const u32 bo = ph + lane, rr = (bo * 43691u) >> 17; co[q0 + lane] = (u8)(rw[gidx + rr] >> (8 * (bo - 3 * rr))); }
+            else co[q0 + lane] = (u8)rw[gidx + lane];
+        }
+    }
+}
+
 int make_params(i64 A0, i64 A1, i64 A2, int C, const u8* colors, int ncolors, int stride, SelParams* p) {
     PB3D_REQUIRE(A0 >= 0 && A1 >= 0 && A2 >= 0 && (C == 1 || C == 3), "pb3d_points: bad shape (%lld,%lld,%lld,%d)",
                  (long long)A0, (long long)A1, (long long)A2, C);
@@ -632,7 +814,15 @@ int pb3d_points_fill_dev(pb3d_ctx* ctx, const uint8_t* d_grid, int64_t A0, int64
     const bool fast16 = stride == 1 && (((uintptr_t)d_grid) & 15u) == 0;
     PB3D_REQUIRE(!fast16 || (ctx->scratch[25] && ctx->scratch_bytes[25] >= (size_t)nb * 256 * sizeof(unsigned short)),
                  "pb3d_points_fill: call pb3d_points_count first");
-    if (fast16 && C == 1)
+    // the wave-private form (k_points_fillw) from round 4 on; knob points_fill = 1: the block form of rounds 2 / 3 (development A/B)
+    const bool wavefill = fast16 && p.nlat <= 0xffffffffll && ctx->tune_points_fill != 1;
+    if (wavefill && C == 1)
+        hipLaunchKernelGGL((k_points_fillw<1>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts, d_cols,
+                           (const unsigned short*)ctx->scratch[25]);
+    else if (wavefill)
+        hipLaunchKernelGGL((k_points_fillw<3>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts, d_cols,
+                           (const unsigned short*)ctx->scratch[25]);
+    else if (fast16 && C == 1)
         hipLaunchKernelGGL((k_points_fill16<1, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_grid, p, (const i64*)ctx->scratch[9], d_pts,
                            d_cols, ScanState{}, (const unsigned short*)ctx->scratch[25]);
     else if (fast16)

@@ -890,6 +890,40 @@ def test_points_colour_sets_hash_probe(pb3d_gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_points_wave_fill_and_block_fill(pb3d_gpu, oracle):
+    """the fill pass of the count -> size -> fill protocol in its wave-private form (k_points_fillw, round 4) and in the block form it
+    replaced (knob points_fill = 1), both against the oracle: rows shorter than a lane's four voxels (several row ends inside one
+    lane), sizes that are not multiples of 4 / 16 / 1024 / 4096, densities from a handful of points per wave (head and tail bytes only)
+    to full, RGB grids and 1-byte label volumes."""
+    from pb3d import labels as L
+    rng = np.random.default_rng(404)
+    PC = oracle.PART_COLORS
+    names = list(PC)
+    pal = np.array([PC[n] for n in names], np.uint8)
+    palette = L.Palette.from_part_colors(PC)
+    shapes = [(1, 1, 1), (2, 3, 1), (7, 5, 2), (129, 2, 3), (5, 1000, 1), (3, 5, 4099), (1, 1, 70001), (64, 64, 64), (31, 7, 130), (9, 1023, 5), (2, 2, 8193)]
+    for shp in shapes:
+        for dens in (0.003, 0.35, 1.0):
+            ids = rng.integers(0, len(pal), shp)
+            grid = pal[ids] * (rng.random(shp) < dens)[..., None].astype(np.uint8)
+            sel = [names[k] for k in rng.choice(len(names), size=int(rng.integers(1, len(names))), replace=False)]
+            op, oc = oracle.get_voxel_points_by_parts(grid, PC, sel)
+            ap, ac, _ = oracle.voxel_grid_to_points(grid, stride=1)
+            lab = L.rgb_to_label(grid, palette)
+            for knob in (0, 1):
+                pb3d_gpu._lib.set_tuning("points_fill", knob)
+                try:
+                    gp, gc = pb3d_gpu.get_voxel_points_by_parts(grid, PC, sel)
+                    assert np.array_equal(gp, op) and np.array_equal(gc, oc), (shp, dens, knob, "parts")
+                    gp, gc, _ = pb3d_gpu.voxel_grid_to_points(grid, stride=1)
+                    assert np.array_equal(gp, ap) and np.array_equal(gc, ac), (shp, dens, knob, "all")
+                    gp, gc = L.get_voxel_points_by_parts_labels(lab, palette, sel)
+                    assert np.array_equal(gp, op) and np.array_equal(gc, oc), (shp, dens, knob, "labels")
+                finally:
+                    pb3d_gpu._lib.set_tuning("points_fill", 0)
+
+
+@pytest.mark.gpu
 def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
     """the fused 90-degree part_carve kernel on shapes the reference's own grids never have (W != D, odd D, non-zero column
     offset of either sign, rows at arbitrary byte alignment), foreign colours included; mixed-angle jobs beside it."""

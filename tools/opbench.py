@@ -195,7 +195,10 @@ def main():
         ms = timeit(both, max(2, a.reps // 2), warm=1)
         fillfrac = npts / nvox
         if "M7" in ops:
-            report("M7", "get_voxel_points_by_parts (10 parts): count + fill", ms, round(3 + 15 * fillfrac, 3), {"points": npts, "fill": round(fillfrac, 4)})
+            ms_fill = timeit(fill, max(3, a.reps), warm=1)          # the fill pass alone (the scanned offsets of the last count stay in the context)
+            ms_cnt = timeit(cnt, max(3, a.reps), warm=1)            # the count pass alone, with its host round trip
+            report("M7", "get_voxel_points_by_parts (10 parts): count + fill", ms, round(3 + 15 * fillfrac, 3),
+                   {"points": npts, "fill": round(fillfrac, 4), "count_pass_ms": round(ms_cnt, 4), "fill_pass_ms": round(ms_fill, 4)})
             n1 = C.c_int64(0)
             one = lambda: L.check(lib.pb3d_points_extract_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), npts,
                                                               C.c_void_p(d_pts.ptr), C.c_void_p(d_pc.ptr), C.byref(n1)))

@@ -64,10 +64,10 @@ def main():
         L, lib = pb3d._lib, pb3d._lib.load()
         ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*([0] * 6))
         rows0["part_carve(6 x 90 deg)"] = (timeit(lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), W, H, D, C.c_void_p(d_ms.ptr),
-                                                                                        C.c_void_p(d_mc.ptr), ang, skip, 6, C.c_void_p(d_pout.ptr))), 10), 9)
+                                                                                        C.c_void_p(d_mc.ptr), ang, skip, 6, C.c_void_p(d_pout.ptr))), 10), 6)   # 6 B/voxel: what the ONE fused sweep moves (PMC)
         ang2 = (C.c_int * 6)(90, 45, 90, 60, 90, 90)
         rows0["part_carve(4 x 90, 45, 60 deg)"] = (timeit(lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), W, H, D, C.c_void_p(d_ms.ptr),
-                                                                                                 C.c_void_p(d_mc.ptr), ang2, skip, 6, C.c_void_p(d_pout.ptr))), 5), 9)
+                                                                                                 C.c_void_p(d_mc.ptr), ang2, skip, 6, C.c_void_p(d_pout.ptr))), 5), 6)
         d_ms.free(); d_mc.free(); d_pout.free()
         rows.update(rows0)
         for name, (ms, bpv) in rows.items():
