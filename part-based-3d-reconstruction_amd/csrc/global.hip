@@ -34,8 +34,8 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     if (nvox == 0 || x1 == x0) return PB3D_OK;
     PB3D_REQUIRE(d_bin_hw && d_rgb_hw3 && d_out_slab, "pb3d_global_carve: null buffer");
     const i64 shape[3] = {W, H, D};
-    if (angle_interval == 90 && W <= 4096) {
-        // angles [0, 90]: both steps are exact permutations on a (w,h,w) grid -> one write-only kernel
+    if (angle_interval == 90) {
+        // angles [0, 90]: both steps are exact permutations on a (w,h,w) grid -> one write-only kernel (k_global_carve90s, csrc/carve.hip)
         double M[9], off[3];
         PB3D_TRY(pb3d_rotinv(90, M));
         PB3D_TRY(pb3d_offset(M, shape, off));
@@ -44,7 +44,7 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     // Other angle steps: the chain of process_voxel_grid on a grid that never exists as bytes before its final (W,H,D,3) form -- the mask
     // bits are written as the bit-sliced volume, the rotation steps run on it, the last one writes the colours (csrc/sliced.hip).
     // Slab outputs need the fused 90-degree path above.
-    PB3D_REQUIRE(x0 == 0 && x1 == W, "pb3d_global_carve: slab output needs the fused 90-degree path (angle_interval=90, w %% 16 == 0)");
+    PB3D_REQUIRE(x0 == 0 && x1 == W, "pb3d_global_carve: slab output needs the fused 90-degree path (angle_interval=90)");
     const int nsteps = 90 / angle_interval + 1;  // len(range(0, 91, k))
     void* mwh;
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));

@@ -189,165 +189,8 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));     // 16-byte access at any byte alignment (rows of odd-sized grids)
 typedef u32 u32_u __attribute__((aligned(1)));
 
-// ------------------------------------------------------------------------------------------------
-// K4: global_carve(binary, rgb, 90) fused: occ[x,y,z] = bm[x,y] && valid(x,z) && bm[c0 - z, y],
-// out = occ ? rgb[y,x,:] : 0 -- write-only, 3 B/voxel.  One wavefront per x-row; lane l owns the
-// 16-byte pieces p = l + 64k of the 3*D-byte column, so every wave store is 1 KiB contiguous.  A
-// piece starts at voxel 16p/3 with channel phase p % 3 and touches 6 voxels; their keep bits come
-// from the image rows bin_hw[y, :] staged in LDS, and the RGBRGB.. / keep byte patterns are cut out
-// of 20-byte sequences with v_alignbyte at the lane's phase.
-// ------------------------------------------------------------------------------------------------
-// RAGGED: 3*D is not a multiple of 16 -- the last piece of a column is short (stored as dwords + bytes); columns then start
-// at arbitrary byte addresses, which 16-byte stores take as they are.
-template <int TYC, bool RAGGED>
-__global__ __launch_bounds__(256) void k_global_carve90v(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3,
-                                                         u8* __restrict__ out_slab, const u32* __restrict__ vbits, int nw, int c0,
-                                                         i64 W, i64 H, i64 D, i64 x_first, i64 x_last) {
-    extern __shared__ __attribute__((aligned(16))) u8 rows[];  // TYC image rows of W bytes
-    const int lane = threadIdx.x & 63;
-    const i64 x = x_first + (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const i64 y_beg = (i64)blockIdx.y * TYC;
-    const i64 y_end = y_beg + TYC < H ? y_beg + TYC : H;
-    {   // stage the image rows of this y-chunk (raw mask bytes; every use tests != 0), 16 bytes per lane when aligned
-        const i64 nb = (y_end - y_beg) * W;
-        const u8* srcp = bin_hw + y_beg * W;
-        // the chunk's rows are one linear run of nb bytes: 16-byte loads at whatever alignment the source has (a byte loop here cost
-        // 22 dependent-latency loads per thread on a 355-wide mask), then the few bytes past the last whole piece
-        for (i64 i = threadIdx.x; i < nb / 16; i += 256) ((u32x4*)rows)[i] = ((const u32x4_u*)srcp)[i];
-        for (i64 i = (nb & ~(i64)15) + threadIdx.x; i < nb; i += 256) rows[i] = srcp[i];
-    }
-    __syncthreads();
-    if (x >= x_last) return;
-    const i64 npieces = (3 * D + 15) / 16;
-    for (i64 pc = lane; pc < npieces; pc += 64) {
-        const int v0 = (int)((16 * pc) / 3);
-        const u32 ph = (u32)(pc % 3);
-        const u32* vr = vbits + x * nw + (v0 >> 5);
-        const u64 win = (u64)vr[0] | ((u64)vr[1] << 32);
-        const u32 vb6 = (u32)(win >> (v0 & 31)) & 0x3fu;
-        for (i64 y = y_beg; y < y_end; ++y) {
-            const u8* row = rows + (y - y_beg) * W;
-            u32 kb = 0;
-            if (row[x]) {
-#pragma unroll
-                for (int e = 0; e < 6; ++e)
-                    if ((vb6 >> e) & 1) kb |= (u32)(row[c0 - (v0 + e)] != 0) << e;
-            }
-            u32x4 r = (u32x4)(0u);
-            if (kb) {
-                const u8* px = rgb_hw3 + (y * W + x) * 3;
-                const u32 R = px[0], G = px[1], B = px[2];
-                const u32 S0 = R | (G << 8) | (B << 16) | (R << 24), S1 = G | (B << 8) | (R << 16) | (G << 24),
-                          S2 = B | (R << 8) | (G << 16) | (B << 24);
-                u32 m[6];
-#pragma unroll
-                for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb >> e) & 1u);
-                const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
-                          w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
-                          w4 = m[5] & 0x0000ffffu;
-                r.x = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w1, w0, ph);
-                r.y = __builtin_amdgcn_alignbyte(S2, S1, ph) & __builtin_amdgcn_alignbyte(w2, w1, ph);
-                r.z = __builtin_amdgcn_alignbyte(S0, S2, ph) & __builtin_amdgcn_alignbyte(w3, w2, ph);
-                r.w = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w4, w3, ph);
-            }
-            u8* op = out_slab + ((x - x_first) * H + y) * D * 3 + 16 * pc;
-            if (!RAGGED || 16 * pc + 16 <= 3 * D) __builtin_nontemporal_store(r, (u32x4_u*)op);
-            else {
-                const u32 t4[4] = {r.x, r.y, r.z, r.w};
-                const int k = (int)(3 * D - 16 * pc);                  // 1..15 bytes
-                for (int j = 0; j < (k >> 2); ++j) *(u32_u*)(op + 4 * j) = t4[j];
-                for (int b = k & ~3; b < k; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4 for columns that are not whole 16-byte pieces (3 * D % 16 != 0: odd widths, the reference's real shapes), FLAT form.  For a fixed
-// x the colour rows (x, y, :, :) of consecutive y follow each other in memory, so a y-chunk of 16 rows is ONE stream of 16 * 3 D bytes
-// -- always a whole number of 16-byte pieces, all of them aligned when H % 16 == 0.  Lanes own pieces of the stream instead of pieces
-// of a row: every wave store is 1 KiB of aligned pieces, no row has a ragged tail.  A piece that straddles two rows is the OR of two
-// one-row pieces, the second one starting before its row (negative byte offset: voxels < 0 are void).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32x4 gc90_piece(const u8* row, u32 rgb24, const u32* vrow, int b, int c0, i64 D, i64 x) {
-    u32x4 r = (u32x4)(0u);
-    if (!row[x]) return r;
-    const int bb = b + 48, q = bb / 3;
-    const int v0 = q - 16;                                   // floor(b / 3): first voxel the piece touches
-    const u32 ph = (u32)(bb - 3 * q);                        // channel of its first byte
-    u32 vb6 = 0;
-    if (v0 > -6 && v0 < D) {
-        const int zs = v0 < 0 ? 0 : v0;
-        const u32* vr = vrow + (zs >> 5);
-        vb6 = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zs & 31)) & 0x3fu;
-        if (v0 < 0) vb6 = (vb6 << (-v0)) & 0x3fu;
-    }
-    u32 kb = 0;
-#pragma unroll
-    for (int e = 0; e < 6; ++e)
-        if ((vb6 >> e) & 1) kb |= (u32)(row[c0 - (v0 + e)] != 0) << e;
-    if (!kb) return r;
-    const u32 R = rgb24 & 0xffu, G = (rgb24 >> 8) & 0xffu, B = rgb24 >> 16;
-    const u32 S0 = R | (G << 8) | (B << 16) | (R << 24), S1 = G | (B << 8) | (R << 16) | (G << 24), S2 = B | (R << 8) | (G << 16) | (B << 24);
-    u32 m[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb >> e) & 1u);
-    const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
-              w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u), w4 = m[5] & 0x0000ffffu;
-    r.x = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w1, w0, ph);
-    r.y = __builtin_amdgcn_alignbyte(S2, S1, ph) & __builtin_amdgcn_alignbyte(w2, w1, ph);
-    r.z = __builtin_amdgcn_alignbyte(S0, S2, ph) & __builtin_amdgcn_alignbyte(w3, w2, ph);
-    r.w = __builtin_amdgcn_alignbyte(S1, S0, ph) & __builtin_amdgcn_alignbyte(w4, w3, ph);
-    return r;
-}
-
-template <int TYC>
-__global__ __launch_bounds__(256) void k_global_carve90f(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3, u8* __restrict__ out_slab,
-                                                         const u32* __restrict__ vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x_first, i64 x_last,
-                                                         pb3d_magic m3D) {
-    extern __shared__ __attribute__((aligned(16))) u8 rows[];  // TYC image rows of W bytes
-    const int lane = threadIdx.x & 63;
-    const i64 x = x_first + (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const i64 y_beg = (i64)blockIdx.y * TYC;                   // H % TYC == 0: every chunk is whole
-    {
-        const i64 nb = (i64)TYC * W;
-        const u8* srcp = bin_hw + y_beg * W;
-        // the chunk's rows are one linear run of nb bytes: 16-byte loads at whatever alignment the source has (a byte loop here cost
-        // 22 dependent-latency loads per thread on a 355-wide mask), then the few bytes past the last whole piece
-        for (i64 i = threadIdx.x; i < nb / 16; i += 256) ((u32x4*)rows)[i] = ((const u32x4_u*)srcp)[i];
-        for (i64 i = (nb & ~(i64)15) + threadIdx.x; i < nb; i += 256) rows[i] = srcp[i];
-    }
-    // ... the colours of the block's 4 x TYC pixels and the validity rows of its 4 x, so that a piece needs no global load at all
-    u32* pxs = (u32*)(rows + (((size_t)TYC * (size_t)W + 15) & ~(size_t)15));      // [4][TYC] packed R | G << 8 | B << 16
-    u32* vbs = pxs + 4 * TYC;                                                      // [4][nw]
-    const i64 xb = x_first + (i64)blockIdx.x * 4;
-    if (threadIdx.x < 4 * TYC) {
-        const int wv = threadIdx.x / TYC, yl = threadIdx.x % TYC;
-        u32 c = 0;
-        if (xb + wv < x_last) { const u8* px = rgb_hw3 + ((y_beg + yl) * W + xb + wv) * 3; c = (u32)px[0] | ((u32)px[1] << 8) | ((u32)px[2] << 16); }
-        pxs[threadIdx.x] = c;
-    }
-    for (int i = threadIdx.x; i < 4 * nw; i += 256) { const int wv = i / nw; vbs[i] = xb + wv < x_last ? vbits[(xb + wv) * nw + (i - wv * nw)] : 0u; }
-    __syncthreads();
-    if (x >= x_last) return;
-    const int rowb = (int)(3 * D);
-    const int npieces = TYC * rowb / 16;
-    const int wv = threadIdx.x >> 6;
-    const u32* vrow = vbs + wv * nw;
-    u8* obase = out_slab + ((x - x_first) * H + y_beg) * D * 3;
-    for (int pc = lane; pc < npieces; pc += 64) {
-        const u32 F = 16u * (u32)pc;
-        const u32 yl = pb3d_div(F, m3D);
-        const int b = (int)(F - yl * m3D.d);
-        const u8* row = rows + yl * W;
-        u32x4 r = gc90_piece(row, pxs[wv * TYC + yl], vrow, b, c0, D, x);
-        if (b + 16 > rowb) {                                   // the piece runs on into the next row of the chunk
-            const u32x4 r2 = gc90_piece(row + W, pxs[wv * TYC + yl + 1], vrow, b - rowb, c0, D, x);
-            r.x |= r2.x; r.y |= r2.y; r.z |= r2.z; r.w |= r2.w;
-        }
-        __builtin_nontemporal_store(r, (u32x4*)(obase + 16 * (i64)pc));
-    }
-}
+// (K4, global_carve(binary, rgb, 90): the per-row piece kernels k_global_carve90v / 90f of rounds 1-3 are gone -- the stream kernel
+// k_global_carve90s in csrc/carve.hip is faster on every shape, profiles/r04_global_carve90_stream_vs_piece_kernels.jsonl.)
 
 // ------------------------------------------------------------------------------------------------
 // K2' fast form for the 90-degree map n0 = c0 - z, n2 = x + c2.  Any W, H, D and any pointer alignment: gfx950 serves
@@ -1573,24 +1416,9 @@ int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rg
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     const PermMap pm = perm_map(M, off);
     PB3D_REQUIRE(pm.r00 == 0 && pm.r02 == -1, "pb3d_global_carve: unexpected 90-degree map");
-    constexpr int TYC = 16;
-    const size_t lds = (size_t)TYC * (size_t)W;
-    PB3D_REQUIRE(lds <= 64 * 1024, "pb3d_global_carve: mask too wide for the fused path");
     u32* bits; int nw;
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-    dim3 grid((unsigned)((x1 - x0 + 3) / 4), (unsigned)((H + TYC - 1) / TYC));
-    PB3D_REQUIRE(grid.y <= 65535u, "pb3d_global_carve: grid too large");
-    if ((3 * D) % 16 == 0)
-        hipLaunchKernelGGL((k_global_carve90v<TYC, false>), grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
-                           (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
-    else if (H % TYC == 0 && D >= 16 && (((uintptr_t)d_out_slab) & 15u) == 0 && ctx->tune_misc[2] != 2)    // rows of a y-chunk as one stream of aligned pieces
-        hipLaunchKernelGGL((k_global_carve90f<TYC>), grid, dim3(256), ((lds + 15) & ~(size_t)15) + (size_t)(4 * TYC + 4 * nw) * sizeof(u32), ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab, (const u32*)bits, nw, pm.c0, W, H, D,
-                           x0, x1, pb3d_make_magic((u32)(3 * D)));
-    else
-        hipLaunchKernelGGL((k_global_carve90v<TYC, true>), grid, dim3(256), lds, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
-                           (const u32*)bits, nw, pm.c0, W, H, D, x0, x1);
-    PB3D_CHECK_LAUNCH();
-    return PB3D_OK;
+    return pb3d_launch_gc90_stream(ctx, d_bin_hw, d_rgb_hw3, (const u32*)bits, nw, pm.c0, W, H, D, x0, x1, d_out_slab);
 }
 
 // All-90-degree part_carve in one sweep (K5).  Returns PB3D_EUNSUPPORTED (without an error message of
