@@ -644,6 +644,156 @@ __global__ __launch_bounds__(256) void k_part_multi16(const u32x4* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// part_carve with 90-degree jobs, PLANE-LOCAL form (round 4; reference utils/voxel_carving_utils.py:139-160).
+//   keep[x,y,z] = valid(x,z) && occ[c0 - z, y, x + c2] && (A[x,y] & A[c0 - z, y]) != 0,   out = keep ? colored : 0
+// (csrc/rotate_tiled.hip, K5).  The fused tile kernels transpose 128 x 128 BYTE tiles of occupancy through LDS, two barriers per plane
+// and 384-byte row pieces on both sides; on rows that are not whole lines (the reference's real shapes) they run at 2.2 - 2.8 TB/s.  But
+// only the occupancy BIT has to be transposed, and a Y-plane of bits is a few KB.  One workgroup = (plane y, 128 output rows x0 ..):
+//   A  the 128 source columns x0 + c2 .. of EVERY source row of the plane (384 contiguous bytes per row, 48 per thread) -> 16 occupancy
+//      bits per thread -> S[n0][128 bits] in LDS; meanwhile the job sets of the plane's image row become bit rows over z (ballots)
+//   C  32 x 32 bit blocks of S transposed in registers -> the raw keep rows T[x][z]
+//   D  T & validity bits & job-match rows -> K[x][z bits] (LDS)
+//   E  the 128 output rows leave as whole rows of 3 D contiguous bytes: 16-byte pieces, colours read only where a piece keeps something
+// Every voxel is read once as a source and at most once more as a kept destination, written once: the 6 B/voxel of the fused sweep,
+// without a byte transposition, in rows of >= 1 KB on the store side, for any D, any alignment, W != D.
+// ------------------------------------------------------------------------------------------------
+// 32 x 32 bit transpose in registers (LSB convention): out[c] bit r = in[r] bit c
+__device__ __forceinline__ void transpose32(u32 a[32]) {
+    u32 m = 0x0000ffffu;
+#pragma unroll
+    for (int j = 16; j; j >>= 1, m ^= m << j) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const u32 t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j; a[k + j] ^= t;
+        }
+    }
+}
+
+typedef u32 u32_ua __attribute__((aligned(1)));
+
+__global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ colored, const u32* __restrict__ A, const u32* __restrict__ AT,
+                                                      const u32* __restrict__ vbits, int nwv, int c0, int c2, i64 W, i64 H, i64 D, int nwz, int njobs,
+                                                      pb3d_magic mP, u8* __restrict__ out) {
+    extern __shared__ u32 sm_plane[];
+    u32* S = sm_plane;                                  // [W][4]: bit b of row n0 = occ[n0, y, x0 + c2 + b]
+    unsigned short* S16 = (unsigned short*)S;
+    u32* Jb = S + 4 * W;                                // [32][nwz]: bit z of row j = job j at image pixel (c0 - z, y)
+    u32* Kl = Jb + 32 * nwz;                            // [128][nwz + 1]: keep bits of output row x0 + r over z
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const i64 y = blockIdx.y, x0 = (i64)blockIdx.x * 128;
+    const int pitch = nwz + 1;
+    const i64 nvox = W * H * D;
+    // ---- the job bit rows: 64 z per ballot
+    for (int kk = wv; 64 * kk < D; kk += 4) {
+        const i64 z = 64 * (i64)kk + lane, n = (i64)c0 - z;
+        const u32 a = (z < D && n >= 0 && n < W) ? AT[y * W + n] : 0u;
+        for (int j = 0; j < njobs; ++j) {
+            const u64 b = __ballot((a >> j) & 1u);
+            if (lane == 0) { Jb[j * nwz + 2 * kk] = (u32)b; if (2 * kk + 1 < nwz) Jb[j * nwz + 2 * kk + 1] = (u32)(b >> 32); }
+        }
+    }
+    for (int r = tid; r < 128; r += 256) Kl[r * pitch + nwz] = 0u;
+    // ---- A: occupancy bits of the source columns
+    for (int it = tid; it < 8 * (int)W; it += 256) {
+        const i64 n0 = it >> 3;
+        const int c = it & 7;
+        const i64 n2 = x0 + c2 + 16 * c;                                   // first source column of this thread's 16
+        u32 bits = 0;
+        if (n2 + 15 >= 0 && n2 < D) {
+            const i64 v = (n0 * H + y) * D + n2;
+            u32 w[12];
+            if (n2 >= 0 && n2 + 16 <= D) {
+                const u32x4_u* g = (const u32x4_u*)(colored + 3 * v);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const u32x4 t = g[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) w[q] = 0u;
+                for (int b = 0; b < 48; ++b) { const i64 col = n2 + b / 3; if (col >= 0 && col < D) w[b >> 2] |= (u32)colored[3 * v + b] << (8 * (b & 3)); }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+                bits |= (u32)((__builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1 < 12 ? j + 1 : 0] : 0u, w[j], (u32)sh) << 8) != 0u) << i;
+            }
+        }
+        S16[it] = (unsigned short)bits;
+    }
+    __syncthreads();
+    // ---- C: 32 x 32 blocks: rows i = source rows c0 - 32 k - i (z = 32 k + i), columns = 32 output rows
+    for (int it = tid; it < 4 * nwz; it += 256) {
+        const int k = it >> 2, jb = it & 3;
+        u32 a[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const i64 n0 = (i64)c0 - 32 * k - i;
+            a[i] = (n0 >= 0 && n0 < W) ? S[4 * n0 + jb] : 0u;
+        }
+        transpose32(a);
+#pragma unroll
+        for (int xx = 0; xx < 32; ++xx) Kl[(32 * jb + xx) * pitch + k] = a[xx];
+    }
+    __syncthreads();
+    // ---- D: validity and job match
+    for (int it = tid; it < 128 * nwz; it += 256) {
+        const int xl = it / nwz, k = it - xl * nwz;
+        const i64 x = x0 + xl;
+        u32 kd = 0;
+        const u32 t = Kl[xl * pitch + k];
+        if (x < W && t) {
+            const u32 vb = vbits[x * nwv + k];
+            u32 aj = A[x * H + y], M = 0;
+            while (aj) { const int j = __ffs((int)aj) - 1; M |= Jb[j * nwz + k]; aj &= aj - 1; }
+            kd = t & vb & M;
+        }
+        Kl[xl * pitch + k] = kd;
+    }
+    __syncthreads();
+    // ---- E: the output rows, 16-byte pieces (piece pc of a row: voxels from 16 pc / 3 on, channel phase pc % 3)
+    const int npieces = (int)((3 * D + 15) / 16);
+    const int nrows = (int)(W - x0 < 128 ? W - x0 : 128);
+    for (int it = tid; it < nrows * npieces; it += 256) {
+        const int xl = (int)pb3d_div((u32)it, mP), pc = it - xl * npieces;
+        const i64 x = x0 + xl;
+        const i64 rb = ((x * H + y) * D) * 3 + 16 * (i64)pc;               // byte offset of the piece
+        const int v0 = (16 * pc) / 3;
+        const u32 ph = (u32)(pc % 3);
+        const u32* kr = Kl + xl * pitch + (v0 >> 5);
+        const u32 k0 = kr[0], k1 = (v0 >> 5) + 1 <= nwz ? kr[1] : 0u;
+        const u32 kb6 = (u32)((((u64)k1 << 32) | (u64)k0) >> (v0 & 31)) & 0x3fu;
+        const int nb = 16 * pc + 16 <= 3 * D ? 16 : (int)(3 * D - 16 * pc);       // bytes of this piece (the row's last one may be short)
+        u32x4 val = (u32x4)(0u);
+        if (kb6) {
+            u32x4 src;
+            if (nb == 16 || rb + 16 <= nvox * 3) src = *(const u32x4_u*)(colored + rb);
+            else {
+                u32 t4[4] = {0, 0, 0, 0};
+                for (int b = 0; b < nb; ++b) t4[b >> 2] |= (u32)colored[rb + b] << (8 * (b & 3));
+                src.x = t4[0]; src.y = t4[1]; src.z = t4[2]; src.w = t4[3];
+            }
+            u32 m[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
+            const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
+                      w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
+                      w4 = m[5] & 0x0000ffffu;
+            val.x = src.x & __builtin_amdgcn_alignbyte(w1, w0, ph);
+            val.y = src.y & __builtin_amdgcn_alignbyte(w2, w1, ph);
+            val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
+            val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
+        }
+        if (nb == 16) __builtin_nontemporal_store(val, (u32x4_u*)(out + rb));
+        else {
+            const u32 t4[4] = {val.x, val.y, val.z, val.w};
+            u8* op = out + rb;
+            for (int jj = 0; jj < (nb >> 2); ++jj) *(u32_ua*)(op + 4 * jj) = t4[jj];
+            for (int b = nb & ~3; b < nb; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
@@ -721,6 +871,22 @@ int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_h
                            d_out_slab, d_vbits, nw, c0, W, H, D, x0, 16 * ngroups, nvox);
         PB3D_CHECK_LAUNCH();
     }
+    return PB3D_OK;
+}
+
+// part_carve with 90-degree jobs, plane-local form.  d_A: job sets in (x, y) order, d_AT: the same in (y, x) order, njobs: highest job + 1.
+// *took = 0: shape outside the path's limits (the caller runs the fused tile kernels).
+int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
+                             int nwv, int c0, int c2, u8* d_out, int* took) {
+    *took = 0;
+    const int nwz = (int)((D + 31) / 32);
+    const size_t lds = ((size_t)4 * W + (size_t)32 * nwz + (size_t)128 * (nwz + 1)) * sizeof(u32);
+    const i64 npieces = (3 * D + 15) / 16;
+    if (D < 1 || W < 1 || lds > 64 * 1024 || H > 65535 || W > (1 << 20) || 128 * npieces >= (1ll << 31)) return PB3D_OK;
+    hipLaunchKernelGGL(k_part90_plane, dim3((unsigned)((W + 127) / 128), (unsigned)H), dim3(256), lds, ctx->stream, d_colored, d_A, d_AT, d_vbits, nwv, c0, c2,
+                       W, H, D, nwz, njobs, pb3d_make_magic((u32)npieces), d_out);
+    PB3D_CHECK_LAUNCH();
+    *took = 1;
     return PB3D_OK;
 }
 

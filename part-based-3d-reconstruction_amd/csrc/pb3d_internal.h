@@ -42,6 +42,7 @@ struct pb3d_ctx {
     int tune_ccl_init_blocks;   // knob "ccl_init_blocks": workgroups per CU of the labelling's first pass (0 = 16)
     int tune_ccl_tilecols;      // knob "ccl_tilecols": windows per level of a plane-to-plane merge tile (0 = 32)
     int tune_points_fill;       // knob "points_fill": 1 = the block form of the two-pass fill (k_points_fill16; development A/B)
+    int tune_part90;            // knob "part90": 0 = choose, 1 = the fused tile kernels (k_part90 / k_part90_flat), 2 = the plane-local kernel (csrc/carve.hip, k_part90_plane)
     int tune_ccl_merge;         // knob "ccl_merge": 0 = tile kernels where the rows fit, 1 = always the pairwise kernel (development A/B)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).
@@ -187,6 +188,8 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
 int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
                           const int* job_angle, const int* job_skip, int njobs, u8* d_out);
 int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh);
+int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
+                             int nwv, int c0, int c2, u8* d_out, int* took);
 int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, const u32* d_vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x0,
                             i64 x1, u8* d_out_slab);
 int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, i64 h, i64 w, const double M[9],

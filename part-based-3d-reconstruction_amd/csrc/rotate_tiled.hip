@@ -1236,13 +1236,15 @@ __global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colo
 }
 
 // job_on: bit j = job j takes part (passed by value: a device copy of the flags cost a memcpy and a stream synchronisation per call)
+// AT (optional): the same sets in (y, x) order, for the plane-wise pass of the stream form (csrc/carve.hip, k_part90_keep)
 __global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_sub, const u8* __restrict__ mask_carve,
-                                                    u32 job_on, int nj, i64 npix, u32* __restrict__ A) {
+                                                    u32 job_on, int nj, i64 npix, u32* __restrict__ A, u32* __restrict__ AT, i64 W, i64 H) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (i64)gridDim.x * blockDim.x) {
         u32 a = 0;
         for (int j = 0; j < nj; ++j)
             if (((job_on >> j) & 1u) && mask_sub[(i64)j * npix + i] && mask_carve[(i64)j * npix + i]) a |= 1u << j;
         A[i] = a;
+        if (AT) { const i64 x = i / H, y = i - x * H; AT[y * W + x] = a; }
     }
 }
 
@@ -1454,9 +1456,21 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)(W * H) * sizeof(u32), &A));
     u32 on = 0;
     for (int j = 0; j < 32; ++j) on |= (u32)((j < njobs && !job_skip[j]) ? 1 : 0) << j;
+    // round 4: the plane-local kernel (csrc/carve.hip) where the fused tile kernels are weakest -- rows that are not whole lines (the
+    // reference's real shapes) and grids of 2^29 voxels and more; knob part90: 1 = never, 2 = wherever its limits allow
+    const bool want_stream = rgbsrc && ctx->tune_part90 != 1 && (ctx->tune_part90 == 2 || (ctx->tune_misc[2] == 0 && (D % 128 != 0 || W * H * D >= (1ll << 29))));    // (misc2 pins forms of the tile kernels)
+    void* AT = nullptr;
+    if (want_stream) PB3D_TRY(pb3d_scratch(ctx, 46, (size_t)(W * H) * sizeof(u32), &AT));
     hipLaunchKernelGGL(k_job_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, d_mask_carve, on, njobs, W * H,
-                       (u32*)A);
+                       (u32*)A, (u32*)AT, W, H);
     PB3D_CHECK_LAUNCH();
+    if (want_stream) {
+        int took = 0;
+        int nj = 0;
+        for (int j = 0; j < njobs; ++j) if (!job_skip[j]) nj = j + 1;
+        PB3D_TRY(pb3d_part_carve90_planes(ctx, d_colored, W, H, D, (const u32*)A, (const u32*)AT, nj, (const u32*)bits, nw, pm.c0, pm.c2, d_out, &took));
+        if (took) return PB3D_OK;
+    }
     if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
     // rows that are not whole lines: the (y, z) stream of every x-row in whole lines (H * D % 128 == 0) or, round 3, in whole 16-byte pieces
     // with a ragged last segment (H * D % 16 == 0; tune misc2 = 4: lines only)
