@@ -673,10 +673,12 @@ __device__ __forceinline__ void transpose32(u32 a[32]) {
 
 typedef u32 u32_ua __attribute__((aligned(1)));
 
+template <int UA, int UE>
 __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ colored, const u32* __restrict__ A, const u32* __restrict__ AT,
                                                       const u32* __restrict__ vbits, int nwv, int c0, int c2, i64 W, i64 H, i64 D, int nwz, int njobs,
                                                       pb3d_magic mP, u8* __restrict__ out) {
     extern __shared__ u32 sm_plane[];
+    __shared__ u32x4 mtab[192];
     u32* S = sm_plane;                                  // [W][4]: bit b of row n0 = occ[n0, y, x0 + c2 + b]
     unsigned short* S16 = (unsigned short*)S;
     u32* Jb = S + 4 * W;                                // [32][nwz]: bit z of row j = job j at image pixel (c0 - z, y)
@@ -695,31 +697,62 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
         }
     }
     for (int r = tid; r < 128; r += 256) Kl[r * pitch + nwz] = 0u;
-    // ---- A: occupancy bits of the source columns
-    for (int it = tid; it < 8 * (int)W; it += 256) {
-        const i64 n0 = it >> 3;
-        const int c = it & 7;
-        const i64 n2 = x0 + c2 + 16 * c;                                   // first source column of this thread's 16
-        u32 bits = 0;
-        if (n2 + 15 >= 0 && n2 < D) {
-            const i64 v = (n0 * H + y) * D + n2;
-            u32 w[12];
-            if (n2 >= 0 && n2 + 16 <= D) {
-                const u32x4_u* g = (const u32x4_u*)(colored + 3 * v);
+    // the byte masks of phase E, one 16-byte entry per (channel phase, 6 keep bits): entry of piece phase ph and bits kb6 = bytes 0xff where
+    // the voxel that owns the byte is kept (a piece starts at channel ph of its first voxel)
+    if (tid < 192) {
+        const u32 ph = (u32)tid >> 6, kb6 = (u32)tid & 63u;
+        u32 m[6];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { const u32x4 t = g[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
-            } else {
+        for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
+        const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
+                  w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
+                  w4 = m[5] & 0x0000ffffu;
+        u32x4 e4;
+        e4.x = __builtin_amdgcn_alignbyte(w1, w0, ph); e4.y = __builtin_amdgcn_alignbyte(w2, w1, ph);
+        e4.z = __builtin_amdgcn_alignbyte(w3, w2, ph); e4.w = __builtin_amdgcn_alignbyte(w4, w3, ph);
+        mtab[tid] = e4;
+    }
+    // ---- A: occupancy bits of the source columns.  Four items per thread and pass: all their loads are in flight before the first is used
+    // (one item at a time, a wave had 48 bytes per lane in flight and the pass ran at the memory's latency, not its bandwidth)
+    for (int it0 = tid; it0 < 8 * (int)W; it0 += 256 * UA) {
+        u32 w[UA][12];
+        int mode[UA];                                                       // 0: nothing to read, 1: whole (loaded here), 2: ragged (read byte-wise below)
+        i64 vv[UA], nn2[UA];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) w[q] = 0u;
-                for (int b = 0; b < 48; ++b) { const i64 col = n2 + b / 3; if (col >= 0 && col < D) w[b >> 2] |= (u32)colored[3 * v + b] << (8 * (b & 3)); }
-            }
+        for (int u = 0; u < UA; ++u) {
+            const int it = it0 + 256 * u;
+            const i64 n0 = it >> 3;
+            const i64 n2 = x0 + c2 + 16 * (it & 7);                        // first source column of this item's 16
+            nn2[u] = n2; vv[u] = (n0 * H + y) * D + n2;
+            mode[u] = (it < 8 * (int)W && n2 + 15 >= 0 && n2 < D) ? ((n2 >= 0 && n2 + 16 <= D) ? 1 : 2) : 0;
+            if (mode[u] == 1) {
+                const u32x4_u* g = (const u32x4_u*)(colored + 3 * vv[u]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int j = (3 * i) >> 2, sh = (3 * i) & 3;
-                bits |= (u32)((__builtin_amdgcn_alignbyte(j + 1 < 12 ? w[j + 1 < 12 ? j + 1 : 0] : 0u, w[j], (u32)sh) << 8) != 0u) << i;
+                for (int q = 0; q < 3; ++q) { const u32x4 t = g[q]; w[u][4 * q] = t.x; w[u][4 * q + 1] = t.y; w[u][4 * q + 2] = t.z; w[u][4 * q + 3] = t.w; }
             }
         }
-        S16[it] = (unsigned short)bits;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const int it = it0 + 256 * u;
+            if (it >= 8 * (int)W) continue;
+            u32 bits = 0;
+            if (mode[u]) {
+                if (mode[u] == 2) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) w[u][q] = 0u;
+                    for (int b2 = 0; b2 < 48; ++b2) { const i64 col = nn2[u] + b2 / 3; if (col >= 0 && col < D) w[u][b2 >> 2] |= (u32)colored[3 * vv[u] + b2] << (8 * (b2 & 3)); }
+                }
+                // any(colour > 0) of voxel i = (sum of its three bytes) != 0: v_dot4_u32_u8 against 0x00010101 sums three bytes of a dword
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+                    const u32 v3 = sh == 0 ? w[u][j] : __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[u][j + 1 < 12 ? j + 1 : 0] : 0u, w[u][j], (u32)sh);
+                    const u32 sum = __builtin_amdgcn_udot4(v3, 0x00010101u, 0u, false);
+                    bits |= (sum < 1u ? sum : 1u) << i;
+                }
+            }
+            S16[it] = (unsigned short)bits;
+        }
     }
     __syncthreads();
     // ---- C: 32 x 32 blocks: rows i = source rows c0 - 32 k - i (z = 32 k + i), columns = 32 output rows
@@ -754,42 +787,51 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
     // ---- E: the output rows, 16-byte pieces (piece pc of a row: voxels from 16 pc / 3 on, channel phase pc % 3)
     const int npieces = (int)((3 * D + 15) / 16);
     const int nrows = (int)(W - x0 < 128 ? W - x0 : 128);
-    for (int it = tid; it < nrows * npieces; it += 256) {
-        const int xl = (int)pb3d_div((u32)it, mP), pc = it - xl * npieces;
-        const i64 x = x0 + xl;
-        const i64 rb = ((x * H + y) * D) * 3 + 16 * (i64)pc;               // byte offset of the piece
-        const int v0 = (16 * pc) / 3;
-        const u32 ph = (u32)(pc % 3);
-        const u32* kr = Kl + xl * pitch + (v0 >> 5);
-        const u32 k0 = kr[0], k1 = (v0 >> 5) + 1 <= nwz ? kr[1] : 0u;
-        const u32 kb6 = (u32)((((u64)k1 << 32) | (u64)k0) >> (v0 & 31)) & 0x3fu;
-        const int nb = 16 * pc + 16 <= 3 * D ? 16 : (int)(3 * D - 16 * pc);       // bytes of this piece (the row's last one may be short)
-        u32x4 val = (u32x4)(0u);
-        if (kb6) {
-            u32x4 src;
-            if (nb == 16 || rb + 16 <= nvox * 3) src = *(const u32x4_u*)(colored + rb);
-            else {
-                u32 t4[4] = {0, 0, 0, 0};
-                for (int b = 0; b < nb; ++b) t4[b >> 2] |= (u32)colored[rb + b] << (8 * (b & 3));
-                src.x = t4[0]; src.y = t4[1]; src.z = t4[2]; src.w = t4[3];
-            }
-            u32 m[6];
+    const int total = nrows * npieces;
+    for (int it0 = tid; it0 < total; it0 += 256 * UE) {                        // four pieces per thread and pass, their loads in flight together
+        i64 rb[UE];
+        u32 kb6[UE], ph[UE];
+        int nb[UE];
+        u32x4 src[UE];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
-            const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
-                      w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
-                      w4 = m[5] & 0x0000ffffu;
-            val.x = src.x & __builtin_amdgcn_alignbyte(w1, w0, ph);
-            val.y = src.y & __builtin_amdgcn_alignbyte(w2, w1, ph);
-            val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
-            val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
+        for (int u = 0; u < UE; ++u) {
+            const int it = it0 + 256 * u;
+            kb6[u] = 0; nb[u] = 0; rb[u] = 0; ph[u] = 0; src[u] = (u32x4)(0u);
+            if (it < total) {
+                const int xl = (int)pb3d_div((u32)it, mP), pc = it - xl * npieces;
+                const i64 x = x0 + xl;
+                rb[u] = ((x * H + y) * D) * 3 + 16 * (i64)pc;              // byte offset of the piece
+                const int v0 = (16 * pc) / 3;
+                ph[u] = (u32)(pc % 3);
+                const u32* kr = Kl + xl * pitch + (v0 >> 5);
+                const u32 k0 = kr[0], k1 = (v0 >> 5) + 1 <= nwz ? kr[1] : 0u;
+                kb6[u] = (u32)((((u64)k1 << 32) | (u64)k0) >> (v0 & 31)) & 0x3fu;
+                nb[u] = 16 * pc + 16 <= 3 * D ? 16 : (int)(3 * D - 16 * pc);      // bytes of this piece (the row's last one may be short)
+                if (kb6[u]) {
+                    if (nb[u] == 16 || rb[u] + 16 <= nvox * 3) src[u] = *(const u32x4_u*)(colored + rb[u]);
+                    else {
+                        u32 t4[4] = {0, 0, 0, 0};
+                        for (int b2 = 0; b2 < nb[u]; ++b2) t4[b2 >> 2] |= (u32)colored[rb[u] + b2] << (8 * (b2 & 3));
+                        src[u].x = t4[0]; src[u].y = t4[1]; src[u].z = t4[2]; src[u].w = t4[3];
+                    }
+                }
+            }
         }
-        if (nb == 16) __builtin_nontemporal_store(val, (u32x4_u*)(out + rb));
-        else {
-            const u32 t4[4] = {val.x, val.y, val.z, val.w};
-            u8* op = out + rb;
-            for (int jj = 0; jj < (nb >> 2); ++jj) *(u32_ua*)(op + 4 * jj) = t4[jj];
-            for (int b = nb & ~3; b < nb; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            if (!nb[u]) continue;
+            u32x4 val = (u32x4)(0u);
+            if (kb6[u]) {
+                const u32x4 mk = mtab[64 * ph[u] + kb6[u]];
+                val.x = src[u].x & mk.x; val.y = src[u].y & mk.y; val.z = src[u].z & mk.z; val.w = src[u].w & mk.w;
+            }
+            if (nb[u] == 16) __builtin_nontemporal_store(val, (u32x4_u*)(out + rb[u]));
+            else {
+                const u32 t4[4] = {val.x, val.y, val.z, val.w};
+                u8* op = out + rb[u];
+                for (int jj = 0; jj < (nb[u] >> 2); ++jj) *(u32_ua*)(op + 4 * jj) = t4[jj];
+                for (int b2 = nb[u] & ~3; b2 < nb[u]; ++b2) op[b2] = (u8)(t4[b2 >> 2] >> (8 * (b2 & 3)));
+            }
         }
     }
 }
@@ -882,8 +924,15 @@ int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i
     const int nwz = (int)((D + 31) / 32);
     const size_t lds = ((size_t)4 * W + (size_t)32 * nwz + (size_t)128 * (nwz + 1)) * sizeof(u32);
     const i64 npieces = (3 * D + 15) / 16;
-    if (D < 1 || W < 1 || lds > 64 * 1024 || H > 65535 || W > (1 << 20) || 128 * npieces >= (1ll << 31)) return PB3D_OK;
-    hipLaunchKernelGGL(k_part90_plane, dim3((unsigned)((W + 127) / 128), (unsigned)H), dim3(256), lds, ctx->stream, d_colored, d_A, d_AT, d_vbits, nwv, c0, c2,
+    if (D < 1 || W < 1 || lds > 150 * 1024 || H > 65535 || W > (1 << 20) || 128 * npieces >= (1ll << 31)) return PB3D_OK;
+    if (lds > 60 * 1024 && !ctx->part90_lds_set) {              // (W beyond ~2900: the plane's bits need more than the default 64 KB)
+        PB3D_HIP(hipFuncSetAttribute((const void*)k_part90_plane<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        ctx->part90_lds_set = true;
+    }
+    // items in flight per thread in the source pass / the output pass: 2 / 4 (tools/tybench.py --op part, the nine combinations of 1, 2, 4
+    // interleaved on one box: best or tied at 512 x 278 x 512, 355 x 512 x 355, 512^3 and 1024^3; profiles/r04_part_carve_plane_kernel_unroll_sweep.jsonl)
+    auto kern = k_part90_plane<2, 4>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((W + 127) / 128), (unsigned)H), dim3(256), lds, ctx->stream, d_colored, d_A, d_AT, d_vbits, nwv, c0, c2,
                        W, H, D, nwz, njobs, pb3d_make_magic((u32)npieces), d_out);
     PB3D_CHECK_LAUNCH();
     *took = 1;

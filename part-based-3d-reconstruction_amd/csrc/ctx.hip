@@ -127,9 +127,6 @@ int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     } else if (!strcmp(name, "points_fill")) {
         PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: points_fill is 0 (wave-private fill) or 1 (block form)");
         ctx->tune_points_fill = value;
-    } else if (!strcmp(name, "part90")) {
-        PB3D_REQUIRE(value >= 0 && value <= 2, "pb3d_set_tuning: part90 is 0 (choose), 1 (fused tile kernels) or 2 (plane-local kernel)");
-        ctx->tune_part90 = value;
     } else if (!strcmp(name, "ccl_merge")) {
         PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: ccl_merge is 0 (tile kernels) or 1 (pairwise kernel)");
         ctx->tune_ccl_merge = value;

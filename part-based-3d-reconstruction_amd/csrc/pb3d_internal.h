@@ -34,6 +34,7 @@ struct pb3d_ctx {
     int tune_sliced;            // PB3D_SLICED: 0 = rotation steps on 0/1 data run bit-sliced (csrc/sliced.hip), 1 = never (byte chain, arithmetic kernel)
     int tune_rot90_wide;        // PB3D_ROT90_WIDE: 1 = the 256 x 256-tile form of the 90-degree step (development A/B)
     bool rot90w_lds_set;
+    bool part90_lds_set;        // k_part90_plane has been given its large dynamic LDS limit
     bool rot90wf_lds_set;       // ... and for its form on the rows' (y, z) streams (odd row lengths)
     int tune_s32_order;         // knob "s32_order": 1 = the slice / un-slice passes walk x fastest (round 3's order; development A/B)
     int tune_s32_fuse_last;     // knob "s32_fuse_last": 1 = the chain's last 90-degree step stays a table step (development A/B)
@@ -42,7 +43,6 @@ struct pb3d_ctx {
     int tune_ccl_init_blocks;   // knob "ccl_init_blocks": workgroups per CU of the labelling's first pass (0 = 16)
     int tune_ccl_tilecols;      // knob "ccl_tilecols": windows per level of a plane-to-plane merge tile (0 = 32)
     int tune_points_fill;       // knob "points_fill": 1 = the block form of the two-pass fill (k_points_fill16; development A/B)
-    int tune_part90;            // knob "part90": 0 = choose, 1 = the fused tile kernels (k_part90 / k_part90_flat), 2 = the plane-local kernel (csrc/carve.hip, k_part90_plane)
     int tune_ccl_merge;         // knob "ccl_merge": 0 = tile kernels where the rows fit, 1 = always the pairwise kernel (development A/B)
     // Growable device scratch slots used by the host-pointer entry points (no hipMalloc /
     // hipFree per call once warm).

@@ -869,372 +869,9 @@ __global__ __launch_bounds__(1024) void k_rot90wf(const u8* __restrict__ in, u8*
 //   keep[x,y,z] = valid(x,z) && occ[c0 - z, y, x + c2] && (A[x,y] & A[c0 - z, y]) != 0
 // with occ = any(colored > 0) and A[x,y] = bitset over jobs of (mask_sub_j && mask_carve_j)[x,y]
 // (both the source-side and the destination-side carve of a job use its own masks).
-// Phase A is k_rot90's register transpose of the occupancy tile and produces 16 keep bits per
-// (row, 16-z run) into LDS; phase B re-maps the threads so that each 16-byte piece of an output row is
-// loaded from `colored`, masked (alignbyte patterns at the piece's RGB phase) and stored with 128
-// contiguous bytes per 8 lanes.  Rows whose keep bits are all zero are never read.
+// The sweep itself is k_part90_plane in csrc/carve.hip (round 4: occupancy BITS of a plane transposed, whole output rows); the byte-tile
+// kernels k_part90 / k_part90_flat of rounds 1-3 are gone -- slower on every shape (profiles/r04_part_carve_plane_kernel_vs_tile_kernels.jsonl).
 // ------------------------------------------------------------------------------------------------
-// 16 occupancy bytes (0/1) of 16 RGB voxels held in 12 dwords
-__device__ __forceinline__ u32x4 occ16_of(const u32x4 a, const u32x4 b, const u32x4 c) {
-    const u32 w[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, 0u};
-    u32 o[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = (3 * i) >> 2, sh = (3 * i) & 3;
-        const u32 v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], (u32)sh) & 0x00ffffffu;
-        o[i >> 2] |= (v ? 1u : 0u) << (8 * (i & 3));
-    }
-    u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
-    return r;
-}
-
-// RGBSRC: the source occupancy any(colored > 0) is formed on the fly from the colour grid itself (3 B/voxel read)
-// instead of from a separate occupancy volume.
-// RAGGED = false: D % 16 == 0 and c2 % 16 == 0 (every 16-voxel piece whole); true: any D / c2 -- pieces at arbitrary byte
-// addresses, the piece across a row end read whole inside the volume (its foreign voxels are void under the validity bits),
-// the short last piece of an output row stored as dwords + bytes.
-template <bool RGBSRC, bool RAGGED>
-__global__ __launch_bounds__(256) void k_part90(const u8* __restrict__ colored, const u8* __restrict__ occ, const u32* __restrict__ A,
-                                                const u32* __restrict__ vbits, int nw, int c0, int c2, i64 W, i64 H, i64 D, int TY,
-                                                u8* __restrict__ out, TileMap tm, int blk_on) {
-    extern __shared__ u32 ablk[];          // blk_on: the workgroup's job bits, plane y_beg + p at ablk[256 p + r]; r < 128 a source row, 128 + r an output row
-    __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
-    __shared__ u32 asrc[128];
-    __shared__ __attribute__((aligned(8))) unsigned short keepb[128 * 8 + 4];
-    const int tid = threadIdx.x;
-    i64 zt, xt, yc;
-    if (!tile_of_block(tm, &zt, &xt, &yc)) return;                          // whole workgroup, before any barrier
-    const i64 x0 = xt * 128, z0 = zt * 128;
-    const i64 y_beg = yc * TY;
-    const i64 y_end = y_beg + TY < H ? y_beg + TY : H;
-    const int cb = tid & 7;
-    const i64 rbase = (i64)c0 - (z0 + 127);
-    const i64 scol = x0 + c2 + 16 * cb;
-    const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((RAGGED && scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
-    const i64 nvox_all = W * H * D;
-    const int zg = tid & 7, xg = tid >> 3;
-    const int g = 7 - zg;
-    const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
-    const i64 zo = z0 + 16 * zg;
-    u32 vb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const i64 x = x0 + 4 * xg + i;
-        vb[i] = (x < W && zo < D) ? (vbits[x * nw + (zo >> 5)] >> (zo & 31)) & 0xffffu : 0u;
-    }
-    const i64 row_bytes = ((D - z0 < 128 ? D - z0 : 128)) * 3;   // bytes of one output row inside this tile
-    // The job bits of the workgroup's 128 source rows and 128 output rows at its planes, fetched once (the planes of a row are
-    // neighbours in memory) instead of five more loads per thread and plane, each pixel a line of its own through the L1 the plane's
-    // 48 KB of colours had just emptied (k_rot90w: the same change took 512^3 from 61.6 to 53.1 us).
-    if (blk_on) {
-        const bool srcrow = tid < 128;
-        const i64 row = srcrow ? rbase + tid : x0 + (tid - 128);
-        const bool rok = row >= 0 && row < W;
-        for (i64 y = y_beg; y < y_end; y += 4) {
-            u32 v4[4] = {0, 0, 0, 0};
-            if (rok) {
-                if (y + 4 <= H) { const u32x4 t = *(const u32x4_u*)(A + row * H + y); v4[0] = t.x; v4[1] = t.y; v4[2] = t.z; v4[3] = t.w; }
-                else for (int b = 0; b < 4 && y + b < H; ++b) v4[b] = A[row * H + y + b];
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (y + b < y_end) ablk[256 * (y + b - y_beg) + tid] = v4[b];
-        }
-        __syncthreads();
-    }
-    u32x4 stg[RGBSRC ? 12 : 4];
-    u32 stg_a = 0;
-    u32 stg_d[4] = {0, 0, 0, 0};
-    auto load_plane = [&](i64 y) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const i64 n0 = rbase + (tid >> 3) + 32 * j;
-            const bool ok = cmode && n0 >= 0 && n0 < W;
-            const i64 v0s = (n0 * H + y) * D + scol;                       // first source voxel of the piece
-            const bool whole = !RAGGED || cmode == 2 || (v0s >= 0 && v0s + 16 <= nvox_all);
-            if (RGBSRC) {
-                const u8* sp8 = colored + v0s * 3;
-                if (whole) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) stg[3 * j + k] = ok ? ((const u32x4_u*)sp8)[k] : (u32x4)(0u);
-                } else {
-                    u32 t12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ok)
-                        for (int b = 0; b < 48; ++b)
-                            if (scol + b / 3 >= 0 && scol + b / 3 < D) t12[b >> 2] |= (u32)sp8[b] << (8 * (b & 3));
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { stg[3 * j + k].x = t12[4 * k]; stg[3 * j + k].y = t12[4 * k + 1]; stg[3 * j + k].z = t12[4 * k + 2]; stg[3 * j + k].w = t12[4 * k + 3]; }
-                }
-            } else {
-                const u8* sp8 = occ + v0s;
-                if (whole) stg[j] = ok ? *(const u32x4_u*)sp8 : (u32x4)(0u);
-                else {
-                    u32 t4[4] = {0, 0, 0, 0};
-                    if (ok)
-                        for (int b = 0; b < 16; ++b)
-                            if (scol + b >= 0 && scol + b < D) t4[b >> 2] |= (u32)sp8[b] << (8 * (b & 3));
-                    stg[j].x = t4[0]; stg[j].y = t4[1]; stg[j].z = t4[2]; stg[j].w = t4[3];
-                }
-            }
-        }
-        if (blk_on) return;
-        if (tid < 128) {
-            const i64 n0 = rbase + tid;
-            stg_a = (n0 >= 0 && n0 < W) ? A[n0 * H + y] : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 x = x0 + 4 * xg + i;
-            stg_d[i] = (x < W && vb[i]) ? A[x * H + y] : 0u;
-        }
-    };
-    load_plane(y_beg);
-    for (i64 y = y_beg; y < y_end; ++y) {
-        const u32* ab = ablk + 256 * (y - y_beg);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = (tid >> 3) + 32 * j;
-            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = RGBSRC ? occ16_of(stg[3 * j], stg[3 * j + 1], stg[3 * j + 2]) : stg[j];
-        }
-        if (!blk_on && tid < 128) asrc[tid] = stg_a;
-        u32 adstv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) adstv[i] = blk_on ? ((x0 + 4 * xg + i < W && vb[i]) ? ab[128 + 4 * xg + i] : 0u) : stg_d[i];
-        const u32* asp = blk_on ? ab : asrc;
-        __syncthreads();
-        if (y + 1 < y_end) load_plane(y + 1);
-        // ---- phase A: keep bits of this thread's 4 rows x 16 z
-        u32 d[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 x = x0 + 4 * xg + i;
-            u32 k16 = 0;
-            if (x < W && vb[i]) {
-                const u32 adst = adstv[i];
-                if (adst) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const u32 ob = (d[15 - q] >> (8 * i)) & 0xffu;               // occ[c0 - z, y, x + c2]
-                        const u32 as = asp[16 * g + 15 - q];
-                        if (ob && (as & adst)) k16 |= 1u << q;
-                    }
-                    k16 &= vb[i];
-                }
-            }
-            keepb[(4 * xg + i) * 8 + zg] = (unsigned short)k16;
-        }
-        __syncthreads();
-        // ---- phase B: row r = (tid >> 3) + 32 j, pieces pl, pl + 8, pl + 16 of its 384 bytes
-        const int pl = tid & 7;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (tid >> 3) + 32 * j;
-            const i64 x = x0 + r;
-            if (x >= W) continue;
-            const u8* srow = colored + ((x * H + y) * D + z0) * 3;
-            u8* drow = out + ((x * H + y) * D + z0) * 3;
-            const unsigned short* kb = keepb + r * 8;
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int pc = pl + 8 * kk;
-                if (RAGGED ? (i64)16 * pc >= row_bytes : (i64)16 * pc + 16 > row_bytes) continue;
-                const int nb = RAGGED && (i64)16 * pc + 16 > row_bytes ? (int)(row_bytes - 16 * pc) : 16;   // bytes of this piece
-                const int v0 = (16 * pc) / 3;
-                const u32 ph = (u32)(pc % 3);
-                const int wi = v0 >> 4;
-                const u32 win = (u32)kb[wi] | ((wi < 7 ? (u32)kb[wi + 1] : 0u) << 16);
-                const u32 kb6 = (win >> (v0 & 15)) & 0x3fu;
-                u32x4 val = (u32x4)(0u);
-                if (kb6) {
-                    u32x4 src;
-                    if (nb == 16 || ((x * H + y) * D + z0) * 3 + 16 * pc + 16 <= nvox_all * 3) src = *(const u32x4_u*)(srow + 16 * pc);
-                    else {
-                        u32 t4[4] = {0, 0, 0, 0};
-                        for (int b = 0; b < nb; ++b) t4[b >> 2] |= (u32)srow[16 * pc + b] << (8 * (b & 3));
-                        src.x = t4[0]; src.y = t4[1]; src.z = t4[2]; src.w = t4[3];
-                    }
-                    u32 m[6];
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
-                    const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
-                              w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
-                              w4 = m[5] & 0x0000ffffu;
-                    val.x = src.x & __builtin_amdgcn_alignbyte(w1, w0, ph);
-                    val.y = src.y & __builtin_amdgcn_alignbyte(w2, w1, ph);
-                    val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
-                    val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
-                }
-                if (nb == 16) __builtin_nontemporal_store(val, (u32x4_u*)(drow + 16 * pc));
-                else {
-                    const u32 t4[4] = {val.x, val.y, val.z, val.w};
-                    u8* op = drow + 16 * pc;
-                    for (int jj = 0; jj < (nb >> 2); ++jj) *(u32_u*)(op + 4 * jj) = t4[jj];
-                    for (int b = nb & ~3; b < nb; ++b) op[b] = (u8)(t4[b >> 2] >> (8 * (b & 3)));
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// K5 for rows that are not whole lines, FLAT form (H * D % 128 == 0; see k_rot90_flat): a tile is 128 x-rows x one SEGMENT of 128
-// voxels of the rows' (y, z) stream, f = y * D + z = 128 s + j.  Source row of byte j: n0 = c0 - z_j of plane y_j; both the colour
-// rows the keep bits are cut from and the rows they are written to are then whole aligned lines (384 bytes per row and segment), so
-// phase B has neither ragged pieces nor partial stores.  A 16-voxel run that straddles a row end takes its destination job bits
-// from two planes.
-__global__ __launch_bounds__(256) void k_part90_flat(const u8* __restrict__ colored, const u32* __restrict__ A, const u32* __restrict__ vbits, int nw,
-                                                     int c0, int c2, i64 W, i64 H, i64 D, int TS, u8* __restrict__ out, TileMap tm, pb3d_magic mD,
-                                                     i64 nseg) {
-    __shared__ __attribute__((aligned(16))) u8 tile[128 * 128];
-    __shared__ u32 asrc[128];
-    __shared__ __attribute__((aligned(8))) unsigned short keepb[128 * 8 + 4];
-    const int tid = threadIdx.x;
-    i64 zt, xt, sc;
-    if (!tile_of_block(tm, &zt, &xt, &sc)) return;                          // whole workgroup, before any barrier
-    const i64 x0 = xt * 128;
-    const i64 s_beg = sc * TS;
-    const i64 s_end = s_beg + TS < nseg ? s_beg + TS : nseg;
-    const i64 HD = H * D;
-    const int cb = tid & 7;
-    const i64 scol = x0 + c2 + 16 * cb;
-    const int cmode = (scol >= 0 && scol + 15 < D) ? 2 : ((scol + 15 >= 0 && scol < D) ? 1 : 0);   // whole / ragged / outside
-    const i64 nvox_all = W * HD;
-    const int zg = tid & 7, xg = tid >> 3;
-    const int g = 7 - zg;
-    const u32 rd_off = (u32)(16 * g * 128 + 16 * ((xg >> 2) ^ g) + 4 * (xg & 3));
-    auto vwin = [&](i64 x, i64 zlo) -> u32 {
-        if (zlo <= -16 || zlo >= D) return 0u;
-        const i64 zs = zlo < 0 ? 0 : zlo;
-        const u32* vr = vbits + x * nw + (zs >> 5);
-        u32 v = (u32)((((u64)vr[1] << 32) | (u64)vr[0]) >> (zs & 31)) & 0xffffu;
-        if (zlo < 0) v = (v << (int)(-zlo)) & 0xffffu;
-        return v;
-    };
-    u32x4 stg[12];
-    u32 stg_a = 0;
-    u32 stg_va[4], stg_da[4], stg_db[4];       // per output row: validity bits of the run, destination job bits of its two planes
-    int stg_nA = 16;
-    auto load_seg = [&](i64 s) {
-        const bool live = s < s_end;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = (tid >> 3) + 32 * j;
-            const u32 f = (u32)(128 * s) + (u32)(127 - lr);
-            const u32 y = pb3d_div(f, mD), z = f - y * mD.d;
-            const i64 n0 = (i64)c0 - (i64)z;
-            const bool ok = live && (i64)f < HD && cmode && n0 >= 0 && n0 < W;      // (f >= H * D: the ragged last segment of a stream that is not whole lines)
-            const i64 v0s = (n0 * H + (i64)y) * D + scol;                  // first source voxel of the piece
-            const bool whole = cmode == 2 || (v0s >= 0 && v0s + 16 <= nvox_all);
-            const u8* sp8 = colored + v0s * 3;
-            if (whole) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) stg[3 * j + k] = ok ? ((const u32x4_u*)sp8)[k] : (u32x4)(0u);
-            } else {
-                u32 t12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok)
-                    for (int b = 0; b < 48; ++b)
-                        if (scol + b / 3 >= 0 && scol + b / 3 < D) t12[b >> 2] |= (u32)sp8[b] << (8 * (b & 3));
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { stg[3 * j + k].x = t12[4 * k]; stg[3 * j + k].y = t12[4 * k + 1]; stg[3 * j + k].z = t12[4 * k + 2]; stg[3 * j + k].w = t12[4 * k + 3]; }
-            }
-        }
-        if (tid < 128) {                                                   // job bits of the source pixel of local row tid
-            const u32 f = (u32)(128 * s) + (u32)(127 - tid);
-            const bool fin = live && (i64)f < HD;
-            const u32 y = fin ? pb3d_div(f, mD) : 0u, z = fin ? f - y * mD.d : 0u;
-            const i64 n0 = (i64)c0 - (i64)z;
-            stg_a = (fin && n0 >= 0 && n0 < W) ? A[n0 * H + (i64)y] : 0u;
-        }
-        const u32 f = (u32)(128 * s) + (u32)(16 * zg);
-        const bool pin = live && (i64)f < HD;                               // this thread's piece lies inside the stream (H * D % 16 == 0: whole or absent)
-        const u32 y = pin ? pb3d_div(f, mD) : 0u, z = pin ? f - y * mD.d : 0u;
-        stg_nA = (i64)z + 16 <= D ? 16 : (int)(D - (i64)z);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 x = x0 + 4 * xg + i;
-            u32 bits = 0, da = 0, db = 0;
-            if (pin && x < W) {
-                bits = vwin(x, (i64)z);
-                if (stg_nA < 16) bits |= vwin(x, (i64)z - D);
-                if (bits) { da = A[x * H + (i64)y]; if (stg_nA < 16) db = A[x * H + (i64)y + 1]; }
-            }
-            stg_va[i] = bits; stg_da[i] = da; stg_db[i] = db;
-        }
-    };
-    load_seg(s_beg);
-    for (i64 s = s_beg; s < s_end; ++s) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lr = (tid >> 3) + 32 * j;
-            *(u32x4*)(tile + lr * 128 + 16 * (cb ^ ((lr >> 4) & 7))) = occ16_of(stg[3 * j], stg[3 * j + 1], stg[3 * j + 2]);
-        }
-        if (tid < 128) asrc[tid] = stg_a;
-        u32 va[4], da[4], db[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { va[i] = stg_va[i]; da[i] = stg_da[i]; db[i] = stg_db[i]; }
-        const int nA = stg_nA;
-        __syncthreads();
-        load_seg(s + 1);
-        // ---- phase A: keep bits of this thread's 4 rows x 16 voxels of the segment
-        u32 d[16];
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) d[rr] = *(const u32*)(tile + rd_off + rr * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32 k16 = 0;
-            if (va[i] && (da[i] | db[i])) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const u32 ob = (d[15 - q] >> (8 * i)) & 0xffu;               // occ[c0 - z, y, x + c2]
-                    const u32 as = asrc[16 * g + 15 - q];
-                    if (ob && (as & (q < nA ? da[i] : db[i]))) k16 |= 1u << q;
-                }
-                k16 &= va[i];
-            }
-            keepb[(4 * xg + i) * 8 + zg] = (unsigned short)k16;
-        }
-        __syncthreads();
-        // ---- phase B: row r = (tid >> 3) + 32 j, pieces pl, pl + 8, pl + 16 of its 384 bytes: whole aligned lines on both sides
-        const int pl = tid & 7;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (tid >> 3) + 32 * j;
-            const i64 x = x0 + r;
-            if (x >= W) continue;
-            const i64 rowoff = (x * HD + 128 * s) * 3;
-            const unsigned short* kb = keepb + r * 8;
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int pc = pl + 8 * kk;
-                const int v0 = (16 * pc) / 3;
-                const u32 ph = (u32)(pc % 3);
-                const int wi = v0 >> 4;
-                const u32 win = (u32)kb[wi] | ((wi < 7 ? (u32)kb[wi + 1] : 0u) << 16);
-                const u32 kb6 = (win >> (v0 & 15)) & 0x3fu;
-                if ((128 * s) * 3 + 16 * pc >= HD * 3) continue;                     // (a piece past the stream's end: ragged last segment only)
-                u32x4 val = (u32x4)(0u);
-                if (kb6) {
-                    const u32x4 src = *(const u32x4*)(colored + rowoff + 16 * pc);
-                    u32 m[6];
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) m[e] = 0u - ((kb6 >> e) & 1u);
-                    const u32 w0 = (m[0] & 0x00ffffffu) | (m[1] & 0xff000000u), w1 = (m[1] & 0x0000ffffu) | (m[2] & 0xffff0000u),
-                              w2 = (m[2] & 0x000000ffu) | (m[3] & 0xffffff00u), w3 = (m[4] & 0x00ffffffu) | (m[5] & 0xff000000u),
-                              w4 = m[5] & 0x0000ffffu;
-                    val.x = src.x & __builtin_amdgcn_alignbyte(w1, w0, ph);
-                    val.y = src.y & __builtin_amdgcn_alignbyte(w2, w1, ph);
-                    val.z = src.z & __builtin_amdgcn_alignbyte(w3, w2, ph);
-                    val.w = src.w & __builtin_amdgcn_alignbyte(w4, w3, ph);
-                }
-                __builtin_nontemporal_store(val, (u32x4*)(out + rowoff + 16 * pc));
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // job_on: bit j = job j takes part (passed by value: a device copy of the flags cost a memcpy and a stream synchronisation per call)
 // AT (optional): the same sets in (y, x) order, for the plane-wise pass of the stream form (csrc/carve.hip, k_part90_keep)
 __global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_sub, const u8* __restrict__ mask_carve,
@@ -1443,59 +1080,23 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
     const PermMap pm = perm_map(M, off);
     const bool rot90 = pm.r00 == 0 && pm.r02 == -1 && pm.r20 == 1 && pm.r22 == 0;
     if (!(rot90 && W <= 65535 * 128 && H <= 65535)) return PB3D_EUNSUPPORTED;
-    const bool ragged = !(D % 16 == 0 && pm.c2 % 16 == 0);
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
     u32* bits; int nw;
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-    void *occ = nullptr, *A;
-#ifndef PB3D_PART90_RGBSRC
-#define PB3D_PART90_RGBSRC 1
-#endif
-    const bool rgbsrc = PB3D_PART90_RGBSRC != 0;
-    if (!rgbsrc) PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)(W * H * D), &occ));
+    void *A, *AT;
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)(W * H) * sizeof(u32), &A));
+    PB3D_TRY(pb3d_scratch(ctx, 46, (size_t)(W * H) * sizeof(u32), &AT));
     u32 on = 0;
-    for (int j = 0; j < 32; ++j) on |= (u32)((j < njobs && !job_skip[j]) ? 1 : 0) << j;
-    // round 4: the plane-local kernel (csrc/carve.hip) where the fused tile kernels are weakest -- rows that are not whole lines (the
-    // reference's real shapes) and grids of 2^29 voxels and more; knob part90: 1 = never, 2 = wherever its limits allow
-    const bool want_stream = rgbsrc && ctx->tune_part90 != 1 && (ctx->tune_part90 == 2 || (ctx->tune_misc[2] == 0 && (D % 128 != 0 || W * H * D >= (1ll << 29))));    // (misc2 pins forms of the tile kernels)
-    void* AT = nullptr;
-    if (want_stream) PB3D_TRY(pb3d_scratch(ctx, 46, (size_t)(W * H) * sizeof(u32), &AT));
+    int nj = 0;
+    for (int j = 0; j < 32; ++j) {
+        const bool live = j < njobs && !job_skip[j];
+        on |= (u32)(live ? 1 : 0) << j;
+        if (live) nj = j + 1;
+    }
     hipLaunchKernelGGL(k_job_bitset, dim3(pb3d_stream_blocks(ctx, W * H, 256, 8)), dim3(256), 0, ctx->stream, d_mask_sub, d_mask_carve, on, njobs, W * H,
                        (u32*)A, (u32*)AT, W, H);
     PB3D_CHECK_LAUNCH();
-    if (want_stream) {
-        int took = 0;
-        int nj = 0;
-        for (int j = 0; j < njobs; ++j) if (!job_skip[j]) nj = j + 1;
-        PB3D_TRY(pb3d_part_carve90_planes(ctx, d_colored, W, H, D, (const u32*)A, (const u32*)AT, nj, (const u32*)bits, nw, pm.c0, pm.c2, d_out, &took));
-        if (took) return PB3D_OK;
-    }
-    if (!rgbsrc) PB3D_TRY(pb3d_occupancy_dev(ctx, d_colored, W * H * D, (u8*)occ));
-    // rows that are not whole lines: the (y, z) stream of every x-row in whole lines (H * D % 128 == 0) or, round 3, in whole 16-byte pieces
-    // with a ragged last segment (H * D % 16 == 0; tune misc2 = 4: lines only)
-    if (rgbsrc && D % 128 != 0 && ((H * D) % 128 == 0 || ((H * D) % 16 == 0 && ctx->tune_misc[2] != 4)) && D >= 128 && H * D < (1ll << 31) - 256 &&
-        ctx->tune_misc[2] != 2 && ((((uintptr_t)d_colored) | ((uintptr_t)d_out)) & 15u) == 0) {
-        const i64 nseg = (H * D + 127) / 128, nxt = (W + 127) / 128;
-        const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
-        const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
-        hipLaunchKernelGGL(k_part90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_colored, (const u32*)A, (const u32*)bits, nw, pm.c0, pm.c2, W,
-                           H, D, TS, d_out, fm, pb3d_make_magic((u32)D), nseg);
-        PB3D_CHECK_LAUNCH();
-        return PB3D_OK;
-    }
-    const i64 tiles = ((D + 127) / 128) * ((W + 127) / 128);
-    int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_misc[1]);
-    // (tools/tybench.py --op part, fills interleaved: 1024^3 1.717 ms at 8 workgroups per CU in the grid -- 32 planes each --, 1.685 at 12,
-    // 1.673 at 16, 1.664 at 24; 512-class grids, 4 planes each at 8, do not care)
-    if (ctx->tune_misc[1] <= 0)
-        for (int fill = 16; TY > 12 && fill <= 32; fill += 8) TY = planes_per_chunk(H, tiles, ctx->cus, 32, fill);
-    const TileMap tm = {(int)((D + 127) / 128), (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2]};
-    dim3 grid(tilemap_blocks(tm));
-    auto kern = rgbsrc ? (ragged ? k_part90<true, true> : k_part90<true, false>) : (ragged ? k_part90<false, true> : k_part90<false, false>);
-    const int blk_on = TY <= 32 && ctx->tune_misc[5] != 16;             // the workgroup's job bits in LDS: 1 KB per plane (three workgroups per CU stay resident)
-    hipLaunchKernelGGL(kern, grid, dim3(256), blk_on ? (size_t)TY * 1024 : 0, ctx->stream, d_colored, (const u8*)occ, (const u32*)A, (const u32*)bits, nw, pm.c0, pm.c2,
-                       W, H, D, TY, d_out, tm, blk_on);
-    PB3D_CHECK_LAUNCH();
-    return PB3D_OK;
+    int took = 0;
+    PB3D_TRY(pb3d_part_carve90_planes(ctx, d_colored, W, H, D, (const u32*)A, (const u32*)AT, nj, (const u32*)bits, nw, pm.c0, pm.c2, d_out, &took));
+    return took ? PB3D_OK : PB3D_EUNSUPPORTED;          // (a plane of bits that does not fit the LDS: the caller's per-job pipeline)
 }

@@ -958,19 +958,17 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
 
 
 @pytest.mark.gpu
-def test_part_carve_three_streams_and_tile_kernels(pb3d_gpu, oracle):
-    """part_carve with 90-degree jobs in its two forms -- the plane-local kernel of round 4 (occupancy BITS of a plane's source columns in
-    LDS, 32 x 32 bit blocks transposed in registers, whole output rows; knob part90 = 2) and the fused tile kernels (part90 = 1) -- against
-    the oracle: W != D with column offsets of
-    either sign, rows of 16 .. 400 voxels at every alignment (rows that are whole dwords of bits, rows that share dwords with their
-    neighbours in memory), more output rows than one 128-row workgroup, volumes that end inside a 16-voxel group, foreign colours, sparse and
-    dense grids, skipped jobs and jobs whose masks overlap."""
+def test_part_carve_plane_kernel(pb3d_gpu, oracle):
+    """part_carve with 90-degree jobs through the plane-local kernel of round 4 (k_part90_plane: occupancy BITS of a plane's source columns
+    in LDS, 32 x 32 bit blocks transposed in registers, whole output rows) against the oracle: W != D with column offsets of either sign,
+    rows of 16 .. 400 voxels at every alignment, more output rows than one 128-row workgroup, rows shorter than a 16-byte piece's six
+    voxels apart, foreign colours, sparse and dense grids, skipped jobs and jobs whose masks overlap."""
     rng = np.random.default_rng(2024)
     PC = oracle.PART_COLORS
     names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
     pal = np.array([PC[n] for n in names] + [(0, 0, 0), (9, 9, 9)], np.uint8)
     shapes = [(37, 9, 51), (51, 5, 37), (130, 6, 62), (129, 3, 131), (16, 7, 48), (200, 3, 72), (64, 5, 64), (96, 4, 32), (33, 3, 16), (17, 5, 17),
-              (355, 4, 355), (131, 16, 131), (300, 3, 172), (172, 3, 300), (260, 2, 260), (128, 2, 128), (19, 1, 23), (400, 1, 400)]
+              (355, 4, 355), (131, 16, 131), (300, 3, 172), (172, 3, 300), (260, 2, 260), (128, 2, 128), (19, 1, 23), (400, 1, 400), (5, 3, 7), (9, 2, 3)]
     for (W, H, D) in shapes:
         for dens in (0.15, 0.8):
             sem = pal[rng.integers(0, 7, (H, W))]
@@ -978,13 +976,8 @@ def test_part_carve_three_streams_and_tile_kernels(pb3d_gpu, oracle):
             colored[rng.random((W, H, D)) > dens] = 0
             for jobs in (JOBS_NB1, [(["dome", "plinth"], 90), (["dome"], 90)], [(["windows"], 90)]):
                 want = oracle.part_carve(colored, sem, jobs)
-                for knob in (2, 1):
-                    pb3d_gpu._lib.set_tuning("part90", knob)
-                    try:
-                        got = pb3d_gpu.part_carve(colored, sem, jobs)
-                    finally:
-                        pb3d_gpu._lib.set_tuning("part90", 0)
-                    assert np.array_equal(got, want), (W, H, D, dens, len(jobs), knob, int((got != want).sum()))
+                got = pb3d_gpu.part_carve(colored, sem, jobs)
+                assert np.array_equal(got, want), (W, H, D, dens, len(jobs), int((got != want).sum()))
 
 
 @pytest.mark.gpu
