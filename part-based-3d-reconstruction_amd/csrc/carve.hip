@@ -724,7 +724,9 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
             const i64 n0 = it >> 3;
             const i64 n2 = x0 + c2 + 16 * (it & 7);                        // first source column of this item's 16
             nn2[u] = n2; vv[u] = (n0 * H + y) * D + n2;
-            mode[u] = (it < 8 * (int)W && n2 + 15 >= 0 && n2 < D) ? ((n2 >= 0 && n2 + 16 <= D) ? 1 : 2) : 0;
+            // 16 voxels that run over a row end are read whole while they stay inside the volume (the foreign ones are masked off below):
+            // a byte loop here is executed by every wave that holds ONE such item -- all of them on a 355-wide grid
+            mode[u] = (it < 8 * (int)W && n2 + 15 >= 0 && n2 < D) ? ((vv[u] >= 0 && vv[u] + 16 <= nvox) ? 1 : 2) : 0;
             if (mode[u] == 1) {
                 const u32x4_u* g = (const u32x4_u*)(colored + 3 * vv[u]);
 #pragma unroll
@@ -750,6 +752,8 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
                     const u32 sum = __builtin_amdgcn_udot4(v3, 0x00010101u, 0u, false);
                     bits |= (sum < 1u ? sum : 1u) << i;
                 }
+                const int ilo = nn2[u] < 0 ? (int)(-nn2[u]) : 0, ihi = D - nn2[u] < 16 ? (int)(D - nn2[u]) : 16;     // the columns that exist: [ilo, ihi)
+                bits &= ((1u << ihi) - 1u) & ~((1u << ilo) - 1u);
             }
             S16[it] = (unsigned short)bits;
         }

@@ -12,6 +12,10 @@
 //         unsigned:           acc > 0 ? acc + 0.5 : 0, clipped to [0, MAX], truncated
 //         signed:             acc > 0 ? acc + 0.5 : acc - 0.5, clipped to [MIN, MAX], truncated
 //         complex:            real and imaginary parts separately (scipy/ndimage/_interpolation.py transforms them one after the other)
+// NON-FINITE VALUES are outside the parity contract: SciPy multiplies every one of its (order + 1)^3 taps by its weight, the zero weights
+// and the y + 1 plane included, so an inf or NaN next to a cell turns the cell into NaN (inf * 0); this kernel skips zero-weight taps and
+// never touches the y + 1 plane, so non-finite values go only where taps with NON-ZERO weight carry them (the 0-degree step moves them
+// like any value; at 90 degrees cos = 6e-17 gives the second taps tiny weights, and a non-finite neighbour reaches the cell as in SciPy).  Pinned by tests/test_gpu_parity.py::test_process_typed_non_finite_values_are_carried_not_spread; finite data is byte-exact.
 // and the carve of the step (np.where(mask, g, 0)) in the same store.  64-bit integers beyond 2^53 go through a double exactly as in SciPy;
 // a value that clips to 2^63 / 2^64 is converted out of range there (C leaves the result to the platform) -- not reproduced.
 #include "rot_common.h"

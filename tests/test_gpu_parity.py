@@ -1722,6 +1722,30 @@ def test_rot90_mask_blocks_random_shapes(pb3d_gpu, oracle):
             assert np.array_equal(got, want), (W, H, D, misc5, int((got != want).any(-1).sum()))
 
 
+def test_process_typed_non_finite_values_are_carried_not_spread(pb3d_gpu):
+    """inf / NaN in a float grid (outside the parity contract, csrc/rotate_typed.hip: SciPy multiplies its zero-weight taps too and turns the
+    neighbourhood into NaN): the typed kernel skips zero-weight taps, so a step whose weights are exactly 0 / 1 (the 0-degree step) moves
+    non-finite values like any other value -- the result equals the run on the same grid with finite stand-ins, the stand-ins put back.
+    (At 90 degrees cos = 6e-17: the second taps carry tiny non-zero weights and a non-finite neighbour does reach the cell, there as in SciPy.)"""
+    rng = np.random.default_rng(77)
+    W, H, D = 24, 5, 24
+    m = rng.random((H, W)) < 0.85
+    for dt in ("float32", "float64"):
+        a = (rng.random((W, H, D)) * 100 - 50).astype(dt)
+        b = a.copy()
+        marks = {1234.5: np.inf, -2345.5: -np.inf, 3456.5: np.nan}
+        for sent, val in marks.items():
+            idx = (rng.integers(0, W, 6), rng.integers(0, H, 6), rng.integers(0, D, 6))
+            a[idx] = sent; b[idx] = val
+        for ang in (91, 200):           # any step beyond 90: the 0-degree step alone
+            want = pb3d_gpu.process_voxel_grid(a, m, ang)
+            got = pb3d_gpu.process_voxel_grid(b, m, ang)
+            for sent, val in marks.items():
+                want = np.where(want == np.asarray(sent, dt), np.asarray(val, dt), want)
+            assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, ang)
+            assert np.isfinite(got).sum() == np.isfinite(want).sum()
+
+
 def test_process_voxel_grid_other_dtypes(pb3d_gpu, oracle, golden):
     """process_voxel_grid on grids that are not uint8 (csrc/rotate_typed.hip): the reference's own outputs for every dtype SciPy's
     interpolation takes (fixture f12), then larger seeded grids against the restatement; float16 is refused as SciPy refuses it; a bool
