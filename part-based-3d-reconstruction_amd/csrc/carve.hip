@@ -673,7 +673,8 @@ __device__ __forceinline__ void transpose32(u32 a[32]) {
 
 typedef u32 u32_ua __attribute__((aligned(1)));
 
-template <int UA, int UE>
+// C = 3: `colored` is the (W,H,D,3) colour grid; C = 1: a 1-byte LABEL volume (row N3: occupancy = label != 0, a piece is 16 voxels).
+template <int C, int UA, int UE>
 __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ colored, const u32* __restrict__ A, const u32* __restrict__ AT,
                                                       const u32* __restrict__ vbits, int nwv, int c0, int c2, i64 W, i64 H, i64 D, int nwz, int njobs,
                                                       pb3d_magic mP, u8* __restrict__ out) {
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
     // ---- A: occupancy bits of the source columns.  Four items per thread and pass: all their loads are in flight before the first is used
     // (one item at a time, a wave had 48 bytes per lane in flight and the pass ran at the memory's latency, not its bandwidth)
     for (int it0 = tid; it0 < 8 * (int)W; it0 += 256 * UA) {
-        u32 w[UA][12];
+        u32 w[UA][C == 3 ? 12 : 4];
         int mode[UA];                                                       // 0: nothing to read, 1: whole (loaded here), 2: ragged (read byte-wise below)
         i64 vv[UA], nn2[UA];
 #pragma unroll
@@ -728,9 +729,9 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
             // a byte loop here is executed by every wave that holds ONE such item -- all of them on a 355-wide grid
             mode[u] = (it < 8 * (int)W && n2 + 15 >= 0 && n2 < D) ? ((vv[u] >= 0 && vv[u] + 16 <= nvox) ? 1 : 2) : 0;
             if (mode[u] == 1) {
-                const u32x4_u* g = (const u32x4_u*)(colored + 3 * vv[u]);
+                const u32x4_u* g = (const u32x4_u*)(colored + C * vv[u]);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { const u32x4 t = g[q]; w[u][4 * q] = t.x; w[u][4 * q + 1] = t.y; w[u][4 * q + 2] = t.z; w[u][4 * q + 3] = t.w; }
+                for (int q = 0; q < C; ++q) { const u32x4 t = g[q]; w[u][4 * q] = t.x; w[u][4 * q + 1] = t.y; w[u][4 * q + 2] = t.z; w[u][4 * q + 3] = t.w; }
             }
         }
 #pragma unroll
@@ -741,17 +742,19 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
             if (mode[u]) {
                 if (mode[u] == 2) {
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) w[u][q] = 0u;
-                    for (int b2 = 0; b2 < 48; ++b2) { const i64 col = nn2[u] + b2 / 3; if (col >= 0 && col < D) w[u][b2 >> 2] |= (u32)colored[3 * vv[u] + b2] << (8 * (b2 & 3)); }
+                    for (int q = 0; q < 4 * C; ++q) w[u][q] = 0u;
+                    for (int b2 = 0; b2 < 16 * C; ++b2) { const i64 col = nn2[u] + b2 / C; if (col >= 0 && col < D) w[u][b2 >> 2] |= (u32)colored[C * vv[u] + b2] << (8 * (b2 & 3)); }
                 }
                 // any(colour > 0) of voxel i = (sum of its three bytes) != 0: v_dot4_u32_u8 against 0x00010101 sums three bytes of a dword
+                if constexpr (C == 3) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int j = (3 * i) >> 2, sh = (3 * i) & 3;
-                    const u32 v3 = sh == 0 ? w[u][j] : __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[u][j + 1 < 12 ? j + 1 : 0] : 0u, w[u][j], (u32)sh);
-                    const u32 sum = __builtin_amdgcn_udot4(v3, 0x00010101u, 0u, false);
-                    bits |= (sum < 1u ? sum : 1u) << i;
-                }
+                    for (int i = 0; i < 16; ++i) {
+                        const int j = (3 * i) >> 2, sh = (3 * i) & 3;
+                        const u32 v3 = sh == 0 ? w[u][j] : __builtin_amdgcn_alignbyte(j + 1 < 12 ? w[u][j + 1 < 12 ? j + 1 : 0] : 0u, w[u][j], (u32)sh);
+                        const u32 sum = __builtin_amdgcn_udot4(v3, 0x00010101u, 0u, false);
+                        bits |= (sum < 1u ? sum : 1u) << i;
+                    }
+                } else bits = nonzero16(w[u]);
                 const int ilo = nn2[u] < 0 ? (int)(-nn2[u]) : 0, ihi = D - nn2[u] < 16 ? (int)(D - nn2[u]) : 16;     // the columns that exist: [ilo, ihi)
                 bits &= ((1u << ihi) - 1u) & ~((1u << ilo) - 1u);
             }
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
     }
     __syncthreads();
     // ---- E: the output rows, 16-byte pieces (piece pc of a row: voxels from 16 pc / 3 on, channel phase pc % 3)
-    const int npieces = (int)((3 * D + 15) / 16);
+    const int npieces = (int)((C * D + 15) / 16);
     const int nrows = (int)(W - x0 < 128 ? W - x0 : 128);
     const int total = nrows * npieces;
     for (int it0 = tid; it0 < total; it0 += 256 * UE) {                        // four pieces per thread and pass, their loads in flight together
@@ -804,15 +807,15 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
             if (it < total) {
                 const int xl = (int)pb3d_div((u32)it, mP), pc = it - xl * npieces;
                 const i64 x = x0 + xl;
-                rb[u] = ((x * H + y) * D) * 3 + 16 * (i64)pc;              // byte offset of the piece
-                const int v0 = (16 * pc) / 3;
-                ph[u] = (u32)(pc % 3);
+                rb[u] = ((x * H + y) * D) * C + 16 * (i64)pc;              // byte offset of the piece
+                const int v0 = C == 3 ? (16 * pc) / 3 : 16 * pc;
+                ph[u] = C == 3 ? (u32)(pc % 3) : 0u;
                 const u32* kr = Kl + xl * pitch + (v0 >> 5);
                 const u32 k0 = kr[0], k1 = (v0 >> 5) + 1 <= nwz ? kr[1] : 0u;
-                kb6[u] = (u32)((((u64)k1 << 32) | (u64)k0) >> (v0 & 31)) & 0x3fu;
-                nb[u] = 16 * pc + 16 <= 3 * D ? 16 : (int)(3 * D - 16 * pc);      // bytes of this piece (the row's last one may be short)
+                kb6[u] = (u32)((((u64)k1 << 32) | (u64)k0) >> (v0 & 31)) & (C == 3 ? 0x3fu : 0xffffu);      // keep bits of the piece's 6 / 16 voxels
+                nb[u] = 16 * pc + 16 <= C * D ? 16 : (int)(C * D - 16 * pc);      // bytes of this piece (the row's last one may be short)
                 if (kb6[u]) {
-                    if (nb[u] == 16 || rb[u] + 16 <= nvox * 3) src[u] = *(const u32x4_u*)(colored + rb[u]);
+                    if (nb[u] == 16 || rb[u] + 16 <= nvox * C) src[u] = *(const u32x4_u*)(colored + rb[u]);
                     else {
                         u32 t4[4] = {0, 0, 0, 0};
                         for (int b2 = 0; b2 < nb[u]; ++b2) t4[b2 >> 2] |= (u32)colored[rb[u] + b2] << (8 * (b2 & 3));
@@ -826,7 +829,9 @@ __global__ __launch_bounds__(256) void k_part90_plane(const u8* __restrict__ col
             if (!nb[u]) continue;
             u32x4 val = (u32x4)(0u);
             if (kb6[u]) {
-                const u32x4 mk = mtab[64 * ph[u] + kb6[u]];
+                u32x4 mk;
+                if constexpr (C == 3) mk = mtab[64 * ph[u] + kb6[u]];
+                else { mk.x = spread4(kb6[u] & 15u); mk.y = spread4((kb6[u] >> 4) & 15u); mk.z = spread4((kb6[u] >> 8) & 15u); mk.w = spread4(kb6[u] >> 12); }
                 val.x = src[u].x & mk.x; val.y = src[u].y & mk.y; val.z = src[u].z & mk.z; val.w = src[u].w & mk.w;
             }
             if (nb[u] == 16) __builtin_nontemporal_store(val, (u32x4_u*)(out + rb[u]));
@@ -922,20 +927,21 @@ int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_h
 
 // part_carve with 90-degree jobs, plane-local form.  d_A: job sets in (x, y) order, d_AT: the same in (y, x) order, njobs: highest job + 1.
 // *took = 0: shape outside the path's limits (the caller runs the fused tile kernels).
-int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
+int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
                              int nwv, int c0, int c2, u8* d_out, int* took) {
     *took = 0;
     const int nwz = (int)((D + 31) / 32);
     const size_t lds = ((size_t)4 * W + (size_t)32 * nwz + (size_t)128 * (nwz + 1)) * sizeof(u32);
-    const i64 npieces = (3 * D + 15) / 16;
+    const i64 npieces = (C * D + 15) / 16;
     if (D < 1 || W < 1 || lds > 150 * 1024 || H > 65535 || W > (1 << 20) || 128 * npieces >= (1ll << 31)) return PB3D_OK;
     if (lds > 60 * 1024 && !ctx->part90_lds_set) {              // (W beyond ~2900: the plane's bits need more than the default 64 KB)
-        PB3D_HIP(hipFuncSetAttribute((const void*)k_part90_plane<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        PB3D_HIP(hipFuncSetAttribute((const void*)k_part90_plane<3, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        PB3D_HIP(hipFuncSetAttribute((const void*)k_part90_plane<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ctx->part90_lds_set = true;
     }
     // items in flight per thread in the source pass / the output pass: 2 / 4 (tools/tybench.py --op part, the nine combinations of 1, 2, 4
     // interleaved on one box: best or tied at 512 x 278 x 512, 355 x 512 x 355, 512^3 and 1024^3; profiles/r04_part_carve_plane_kernel_unroll_sweep.jsonl)
-    auto kern = k_part90_plane<2, 4>;
+    auto kern = C == 3 ? k_part90_plane<3, 2, 4> : k_part90_plane<1, 2, 4>;
     hipLaunchKernelGGL(kern, dim3((unsigned)((W + 127) / 128), (unsigned)H), dim3(256), lds, ctx->stream, d_colored, d_A, d_AT, d_vbits, nwv, c0, c2,
                        W, H, D, nwz, njobs, pb3d_make_magic((u32)npieces), d_out);
     PB3D_CHECK_LAUNCH();
@@ -993,7 +999,7 @@ int pb3d_part_carve_dev(pb3d_ctx* ctx, const uint8_t* d_colored, int64_t W, int6
     if (n90 > 0 && njobs <= 32) {
         std::vector<int> skip90(njobs);
         for (int j = 0; j < njobs; ++j) skip90[j] = job_skip[j] || job_angle[j] != 90;
-        const int rc = pb3d_try_part_carve90(ctx, d_colored, W, H, D, d_mask_sub, d_mask_carve, job_angle, skip90.data(), njobs, d_out);
+        const int rc = pb3d_try_part_carve90(ctx, d_colored, 3, W, H, D, d_mask_sub, d_mask_carve, job_angle, skip90.data(), njobs, d_out);
         if (rc != PB3D_EUNSUPPORTED) {
             if (rc != PB3D_OK || nother == 0) return rc;
             base90 = true;

@@ -185,10 +185,10 @@ int pb3d_perm_valid_table(pb3d_ctx* ctx, const double M[9], const double off[3],
 bool pb3d_perm_step_ok(const double M[9], const double off[3], i64 W, i64 D, const void* a, const void* b);
 int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, const double M[9], const double off[3],
                             const u8* d_mask_src, const u8* d_mask_dst, u8* d_out);
-int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
+int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
                           const int* job_angle, const int* job_skip, int njobs, u8* d_out);
 int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh);
-int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
+int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
                              int nwv, int c0, int c2, u8* d_out, int* took);
 int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, const u32* d_vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x0,
                             i64 x1, u8* d_out_slab);

@@ -1062,7 +1062,7 @@ int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rg
 
 // All-90-degree part_carve in one sweep (K5).  Returns PB3D_EUNSUPPORTED (without an error message of
 // its own) when the fast-path conditions do not hold; the caller then runs the per-job pipeline.
-int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
+int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i64 H, i64 D, const u8* d_mask_sub, const u8* d_mask_carve,
                           const int* job_angle, const int* job_skip, int njobs, u8* d_out) {
     if (njobs > 32 || njobs <= 0) return PB3D_EUNSUPPORTED;
     bool any = false;
@@ -1097,6 +1097,6 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, i64 W, i64 H, i64 
                        (u32*)A, (u32*)AT, W, H);
     PB3D_CHECK_LAUNCH();
     int took = 0;
-    PB3D_TRY(pb3d_part_carve90_planes(ctx, d_colored, W, H, D, (const u32*)A, (const u32*)AT, nj, (const u32*)bits, nw, pm.c0, pm.c2, d_out, &took));
+    PB3D_TRY(pb3d_part_carve90_planes(ctx, d_colored, C, W, H, D, (const u32*)A, (const u32*)AT, nj, (const u32*)bits, nw, pm.c0, pm.c2, d_out, &took));
     return took ? PB3D_OK : PB3D_EUNSUPPORTED;          // (a plane of bits that does not fit the LDS: the caller's per-job pipeline)
 }

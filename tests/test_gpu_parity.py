@@ -967,6 +967,8 @@ def test_part_carve_plane_kernel(pb3d_gpu, oracle):
     PC = oracle.PART_COLORS
     names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
     pal = np.array([PC[n] for n in names] + [(0, 0, 0), (9, 9, 9)], np.uint8)
+    lpal = pb3d_gpu.Palette([PC[n] for n in names], names)
+    pal6 = lpal.table()                                                     # label k -> colour (label 0 = black)
     shapes = [(37, 9, 51), (51, 5, 37), (130, 6, 62), (129, 3, 131), (16, 7, 48), (200, 3, 72), (64, 5, 64), (96, 4, 32), (33, 3, 16), (17, 5, 17),
               (355, 4, 355), (131, 16, 131), (300, 3, 172), (172, 3, 300), (260, 2, 260), (128, 2, 128), (19, 1, 23), (400, 1, 400), (5, 3, 7), (9, 2, 3)]
     for (W, H, D) in shapes:
@@ -978,6 +980,19 @@ def test_part_carve_plane_kernel(pb3d_gpu, oracle):
                 want = oracle.part_carve(colored, sem, jobs)
                 got = pb3d_gpu.part_carve(colored, sem, jobs)
                 assert np.array_equal(got, want), (W, H, D, dens, len(jobs), int((got != want).sum()))
+            # the same kernel on 1-byte label volumes (row N3: occupancy = label != 0, 16-voxel pieces) == the RGB result == the per-job label passes
+            ids = rng.integers(0, 7, (W, H, D)).astype(np.uint8) * (rng.random((W, H, D)) < dens)
+            lcol = pal6[ids]
+            lsem = pal6[rng.integers(0, 7, (H, W))]
+            lab_mask = lpal.mask_to_labels(lsem)
+            want = oracle.part_carve(lcol, lsem, JOBS_NB1)
+            got = pb3d_gpu.part_carve_labels(ids, lab_mask, JOBS_NB1, lpal)
+            assert np.array_equal(pb3d_gpu.label_to_rgb(got, lpal), want), (W, H, D, dens, "labels")
+            pb3d_gpu._lib.set_tuning("misc3", 2)
+            try:
+                assert np.array_equal(pb3d_gpu.part_carve_labels(ids, lab_mask, JOBS_NB1, lpal), got), (W, H, D, dens, "labels, per job")
+            finally:
+                pb3d_gpu._lib.set_tuning("misc3", 0)
 
 
 @pytest.mark.gpu

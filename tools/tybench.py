@@ -49,6 +49,17 @@ def main():
             ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*([0] * 6))
             fn = lambda: L.check(lib.pb3d_part_carve_dev(L.ctx(), C.c_void_p(d_col.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_ms.ptr), ang, skip, 6,
                                                          C.c_void_p(d_pout.ptr)))
+        if a.op == "partlabel":      # the same six jobs on a 1-byte label volume (row N3)
+            import ctypes as C
+            m_hw = rng.random((H, W)) < 0.8
+            lab = rng.integers(0, 7, (W, H), dtype=np.uint8) * m_hw.T
+            msub = np.stack([(lab == j + 1).astype(np.uint8) for j in range(6)])
+            d_ms = dev.from_numpy(msub); d_lab = dev.DeviceBuffer(nvox); d_lout = dev.DeviceBuffer(nvox)
+            dev.synth_occ(0, W, H, D, 0, d_lab)                                  # 0 / 1 bytes: labels 0 and 1
+            L, lib = pb3d._lib, pb3d._lib.load()
+            ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*([0] * 6))
+            fn = lambda: L.check(lib.pb3d_part_carve_label_dev(L.ctx(), C.c_void_p(d_lab.ptr), W, H, D, C.c_void_p(d_ms.ptr), C.c_void_p(d_ms.ptr), ang, skip, 6,
+                                                               C.c_void_p(d_lout.ptr)))
         if a.variants:
             sets = [dict(kv.split("=") for kv in v.split(",") if kv) for v in a.variants.split(";")]
             keys = sorted({k for st in sets for k in st})
