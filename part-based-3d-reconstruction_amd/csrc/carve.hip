@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void k_color_apply16(const u8* __restrict__ ca
 // the wave-private window.  Replaces the per-row piece kernels k_global_carve90v / 90f of rounds 1-3, which formed the keep bits of
 // every 16-BYTE piece from six LDS byte reads (355 x 512 x 355: 65 -> 40 us; 1024^3 the same 0.5 ms, it is the 3.2 GB written).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 spread4(u32 b4) { return ((b4 * 0x00204081u) & 0x01010101u) * 0xffu; }      // bit j -> byte j = 0xff
 __device__ __forceinline__ u32 nonzero16(const u32 cw[4]) {      // bit i = (byte i of the 16 bytes != 0)
     u32 bits = 0;
 #pragma unroll
@@ -355,7 +356,8 @@ __device__ __forceinline__ u32 gc90_bits(const u8* __restrict__ brow, const u32*
 }
 
 // FLAT = false: D % 16 == 0, a group lies in one column; true: groups may straddle two columns (two pixels, split at voxel `bnd`)
-template <bool FLAT>
+// C = 3: rgb_hw3 is the (h, w, 3) colour image; C = 1: a (h, w) LABEL image, the output a 1-byte label volume (row N3: 16 bytes per lane)
+template <bool FLAT, int C>
 __global__ __launch_bounds__(256) void k_global_carve90s(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3, u8* __restrict__ out_slab,
                                                          const u32* __restrict__ vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x_first,
                                                          i64 ngroups, pb3d_magic mD, pb3d_magic mH, int small) {
@@ -372,9 +374,26 @@ __global__ __launch_bounds__(256) void k_global_carve90s(const u8* __restrict__ 
             const int z0 = (int)(16 * g - xy * D);
             const i64 bnd = FLAT ? (xy + 1) * D - 16 * g : 16;    // voxels of the group that belong to column xy (>= 16: all)
             const u8* brow = bin_hw + y * W;
-            const u8* px = rgb_hw3 + (y * W + x) * 3;
-            const u32 cr = px[0], cg = px[1], cb = px[2];
+            const u8* px = rgb_hw3 + (y * W + x) * C;
+            const u32 cr = px[0], cg = C == 3 ? px[1] : 0u, cb = C == 3 ? px[2] : 0u;
             const u32 k1 = gc90_bits(brow, vbits + x * nw, x, z0, c0, (int)W);       // (validity bits past D are zero: a straddling group masks itself)
+            if constexpr (C == 1) {
+                u32 k2 = 0, lab2 = 0;
+                if (FLAT && bnd < 16) {
+                    const i64 x1 = y + 1 < H ? x : x + 1, y1 = y + 1 < H ? y + 1 : 0;
+                    const u8* brow1 = bin_hw + y1 * W;
+                    lab2 = rgb_hw3[y1 * W + x1];
+                    k2 = (gc90_bits(brow1, vbits + x1 * nw, x1, 0, c0, (int)W) << bnd) & 0xffffu;
+                }
+                const u32 l1 = cr * 0x01010101u, l2 = lab2 * 0x01010101u;
+                u32x4 o;
+                o.x = (spread4(k1 & 15u) & l1) | (spread4(k2 & 15u) & l2);
+                o.y = (spread4((k1 >> 4) & 15u) & l1) | (spread4((k2 >> 4) & 15u) & l2);
+                o.z = (spread4((k1 >> 8) & 15u) & l1) | (spread4((k2 >> 8) & 15u) & l2);
+                o.w = (spread4(k1 >> 12) & l1) | (spread4(k2 >> 12) & l2);
+                __builtin_nontemporal_store(o, (u32x4_u*)(out_slab + 16 * g));
+                continue;
+            }
             u32 w[12];
             expand16(k1, cr, cg, cb, w);
             if (FLAT && bnd < 16) {
@@ -391,23 +410,21 @@ __global__ __launch_bounds__(256) void k_global_carve90s(const u8* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 3; ++k) { r[k].x = w[4 * k]; r[k].y = w[4 * k + 1]; r[k].z = w[4 * k + 2]; r[k].w = w[4 * k + 3]; }
         }
-        store48_wave((u32x4_u*)out_slab, gw0, ngroups, r, stage[wv]);
+        if constexpr (C == 3) store48_wave((u32x4_u*)out_slab, gw0, ngroups, r, stage[wv]);
     }
 }
 
 // the last nvox % 16 voxels of the slab (and grids with D < 16), voxel by voxel
 __global__ __launch_bounds__(256) void k_global_carve90_generic(const u8* __restrict__ bin_hw, const u8* __restrict__ rgb_hw3, u8* __restrict__ out_slab,
                                                                 const u32* __restrict__ vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x_first,
-                                                                i64 v_first, i64 nvox) {
+                                                                i64 v_first, i64 nvox, int C) {
     for (i64 v = v_first + (i64)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (i64)gridDim.x * blockDim.x) {
         const i64 xy = v / D, z = v - xy * D;
         const i64 xr = xy / H, y = xy - xr * H, x = x_first + xr;
         const i64 n = (i64)c0 - z;
         const bool on = bin_hw[y * W + x] && ((vbits[x * nw + (z >> 5)] >> (z & 31)) & 1u) && n >= 0 && n < W && bin_hw[y * W + n];
-        const u8* px = rgb_hw3 + (y * W + x) * 3;
-        out_slab[3 * v] = on ? px[0] : (u8)0;
-        out_slab[3 * v + 1] = on ? px[1] : (u8)0;
-        out_slab[3 * v + 2] = on ? px[2] : (u8)0;
+        const u8* px = rgb_hw3 + (y * W + x) * C;
+        for (int c = 0; c < C; ++c) out_slab[C * v + c] = on ? px[c] : (u8)0;
     }
 }
 
@@ -473,7 +490,6 @@ __device__ __forceinline__ u32 group_sel16(const u8* __restrict__ mask_sub, i64 
     if (nfirst < 16u) { const u32 lowm = (1u << nfirst) - 1u; sel = (sel & lowm) | (mask_sub[col0 + 1] ? (0xffffu & ~lowm) : 0u); }
     return sel;
 }
-__device__ __forceinline__ u32 spread4(u32 b4) { return ((b4 * 0x00204081u) & 0x01010101u) * 0xffu; }      // bit j -> byte j = 0xff
 
 __global__ __launch_bounds__(256) void k_part_occ16(const u32x4* __restrict__ colored, const u8* __restrict__ mask_sub,
                                                     u32x4* __restrict__ occ, i64 ngroups, pb3d_magic mD) {
@@ -906,12 +922,12 @@ int pb3d_occupancy_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t nvox, u
 }  // extern "C"
 
 // global_carve(., ., 90) on the slab x in [x0, x1): the stream kernel above (d_vbits: the validity table of the 90-degree step)
-int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, const u32* d_vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x0,
+int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, int C, const u32* d_vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x0,
                             i64 x1, u8* d_out_slab) {
     const i64 nvox = (x1 - x0) * H * D;
     const i64 ngroups = (D >= 16 && W >= 16) ? nvox / 16 : 0;
     if (ngroups) {
-        auto kern = D % 16 == 0 ? k_global_carve90s<false> : k_global_carve90s<true>;
+        auto kern = C == 3 ? (D % 16 == 0 ? k_global_carve90s<false, 3> : k_global_carve90s<true, 3>) : (D % 16 == 0 ? k_global_carve90s<false, 1> : k_global_carve90s<true, 1>);
         hipLaunchKernelGGL(kern, dim3(pb3d_stream_blocks(ctx, ngroups, 256, 0)), dim3(256), 0, ctx->stream, d_bin_hw, d_rgb_hw3, d_out_slab,
                            d_vbits, nw, c0, W, H, D, x0, ngroups, pb3d_make_magic((u32)(D < (1ll << 31) ? D : 1)), pb3d_make_magic((u32)(H < (1ll << 31) ? H : 1)),
                            (nvox < (1ll << 32) && D < (1ll << 31) && H < (1ll << 31)) ? 1 : 0);
@@ -919,7 +935,7 @@ int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_h
     }
     if (16 * ngroups < nvox) {
         hipLaunchKernelGGL(k_global_carve90_generic, dim3(pb3d_stream_blocks(ctx, nvox - 16 * ngroups, 256, 8)), dim3(256), 0, ctx->stream, d_bin_hw, d_rgb_hw3,
-                           d_out_slab, d_vbits, nw, c0, W, H, D, x0, 16 * ngroups, nvox);
+                           d_out_slab, d_vbits, nw, c0, W, H, D, x0, 16 * ngroups, nvox, C);
         PB3D_CHECK_LAUNCH();
     }
     return PB3D_OK;

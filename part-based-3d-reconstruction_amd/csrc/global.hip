@@ -39,7 +39,7 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
         double M[9], off[3];
         PB3D_TRY(pb3d_rotinv(90, M));
         PB3D_TRY(pb3d_offset(M, shape, off));
-        if (pb3d_is_perm_step(M, off, W, D)) return pb3d_launch_global_carve90(ctx, d_bin_hw, d_rgb_hw3, h, w, M, off, x0, x1, d_out_slab);
+        if (pb3d_is_perm_step(M, off, W, D)) return pb3d_launch_global_carve90(ctx, d_bin_hw, d_rgb_hw3, 3, h, w, M, off, x0, x1, d_out_slab);
     }
     // Other angle steps: the chain of process_voxel_grid on a grid that never exists as bytes before its final (W,H,D,3) form -- the mask
     // bits are written as the bit-sliced volume, the rotation steps run on it, the last one writes the colours (csrc/sliced.hip).

@@ -312,6 +312,13 @@ int pb3d_global_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const ui
     const i64 W = w, H = h, D = w, nvox = W * H * D;
     if (nvox == 0) return PB3D_OK;
     PB3D_REQUIRE(d_bin_hw && d_label_hw && d_out, "pb3d_global_carve_label: null buffer");
+    if (angle_interval == 90 && ctx->tune_misc[3] != 2) {       // the write-only stream kernel of the RGB form on label bytes (csrc/carve.hip, k_global_carve90s<., 1>)
+        const i64 shape[3] = {W, H, D};
+        double M[9], off[3];
+        PB3D_TRY(pb3d_rotinv(90, M));
+        PB3D_TRY(pb3d_offset(M, shape, off));
+        if (pb3d_is_perm_step(M, off, W, D)) return pb3d_launch_global_carve90(ctx, d_bin_hw, d_label_hw, 1, h, w, M, off, 0, W, d_out);
+    }
     void *ones, *carved, *tmp, *mwh;
     PB3D_TRY(pb3d_scratch(ctx, 4, (size_t)nvox, &ones));
     PB3D_TRY(pb3d_scratch(ctx, 5, (size_t)nvox, &carved));

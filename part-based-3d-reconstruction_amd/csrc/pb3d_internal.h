@@ -190,7 +190,7 @@ int pb3d_try_part_carve90(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i64 
 int pb3d_transpose_mask_dev(pb3d_ctx* ctx, const u8* d_hw, i64 h, i64 w, u8* d_wh);
 int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i64 H, i64 D, const u32* d_A, const u32* d_AT, int njobs, const u32* d_vbits,
                              int nwv, int c0, int c2, u8* d_out, int* took);
-int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, const u32* d_vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x0,
+int pb3d_launch_gc90_stream(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, int C, const u32* d_vbits, int nw, int c0, i64 W, i64 H, i64 D, i64 x0,
                             i64 x1, u8* d_out_slab);
-int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, i64 h, i64 w, const double M[9],
+int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, int C, i64 h, i64 w, const double M[9],
                                const double off[3], i64 x0, i64 x1, u8* d_out_slab);

@@ -1049,7 +1049,7 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
 }
 
 // fused global_carve for angle_interval == 90.  Output slab x in [x0, x1).
-int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, i64 h, i64 w, const double M[9],
+int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rgb_hw3, int C, i64 h, i64 w, const double M[9],
                                const double off[3], i64 x0, i64 x1, u8* d_out_slab) {
     const i64 W = w, H = h, D = w;
     RotParams p = {M[0], M[1], M[2], off[0], M[6], M[7], M[8], off[2]};
@@ -1057,7 +1057,7 @@ int pb3d_launch_global_carve90(pb3d_ctx* ctx, const u8* d_bin_hw, const u8* d_rg
     PB3D_REQUIRE(pm.r00 == 0 && pm.r02 == -1, "pb3d_global_carve: unexpected 90-degree map");
     u32* bits; int nw;
     PB3D_TRY(build_valid_table(ctx, p, W, D, &bits, &nw));
-    return pb3d_launch_gc90_stream(ctx, d_bin_hw, d_rgb_hw3, (const u32*)bits, nw, pm.c0, W, H, D, x0, x1, d_out_slab);
+    return pb3d_launch_gc90_stream(ctx, d_bin_hw, d_rgb_hw3, C, (const u32*)bits, nw, pm.c0, W, H, D, x0, x1, d_out_slab);
 }
 
 // All-90-degree part_carve in one sweep (K5).  Returns PB3D_EUNSUPPORTED (without an error message of

@@ -958,6 +958,32 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_global_carve_90_stream_kernel_rgb_and_labels(pb3d_gpu, oracle):
+    """global_carve(binary, image, 90) through the stream kernel of round 4 (k_global_carve90s), RGB image and 1-byte label image (row N3),
+    against the oracle on widths that are / are not multiples of 16 (groups that straddle two columns, two pixel colours in one group),
+    masks from nearly empty to full, odd heights; the label form also against its composed pipeline (ones -> process -> label apply)."""
+    rng = np.random.default_rng(515)
+    PC = oracle.PART_COLORS
+    names = list(PC)[:6]
+    lpal = pb3d_gpu.Palette([PC[n] for n in names], names)
+    tab = lpal.table()
+    for (h, w) in [(5, 16), (7, 17), (9, 33), (4, 48), (6, 100), (3, 131), (8, 160), (2, 355), (11, 64), (1, 19)]:
+        for dens in (0.05, 0.6, 1.0):
+            lab = (rng.integers(1, 7, (h, w)) * (rng.random((h, w)) < dens)).astype(np.uint8)
+            sem = tab[lab]
+            binary = (lab != 0).astype(np.uint8) * int(rng.integers(1, 255))
+            want = oracle.global_carve(binary, sem, 90)
+            assert np.array_equal(pb3d_gpu.global_carve(binary, sem, 90), want), (h, w, dens)
+            lg = pb3d_gpu.global_carve_labels(binary, lab, 90)
+            assert lg.dtype == np.uint8 and np.array_equal(tab[lg], want), (h, w, dens, "labels")
+            pb3d_gpu._lib.set_tuning("misc3", 2)
+            try:
+                assert np.array_equal(pb3d_gpu.global_carve_labels(binary, lab, 90), lg), (h, w, dens, "labels, composed")
+            finally:
+                pb3d_gpu._lib.set_tuning("misc3", 0)
+
+
+@pytest.mark.gpu
 def test_part_carve_plane_kernel(pb3d_gpu, oracle):
     """part_carve with 90-degree jobs through the plane-local kernel of round 4 (k_part90_plane: occupancy BITS of a plane's source columns
     in LDS, 32 x 32 bit blocks transposed in registers, whole output rows) against the oracle: W != D with column offsets of either sign,
