@@ -55,10 +55,12 @@ void pb3d_destroy(pb3d_ctx* ctx);
 int pb3d_make_current(pb3d_ctx* ctx);
 int pb3d_device_info(pb3d_ctx* ctx, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes);
 int pb3d_sync(pb3d_ctx* ctx);
-/* Development knobs (results never depend on them; they select between kernels that are all bit-exact).  Initial values come
- * from the environment, read ONCE in pb3d_create: PB3D_ROTATE_TILE -> "rotate_tile" (0 = choose by size; 64 / 128 / 256 pin the
- * generic-angle tile kernel -- the parity tests run all of them on the same grids), PB3D_ROT8_TY -> "rot8_ty", PB3D_TUNE0..5 ->
- * "misc0".."misc5". */
+/* Development knobs (results never depend on them; they select between kernels that are all bit-exact, and the parity tests use them to
+ * run both forms of a kernel on the same grids).  Every knob has a name -- "sliced", "rot90_wide", "rot90_flat", "rot90_fill",
+ * "rot90_mask_block", "global_composed", "per_job", "points_fill", "points_onepass", "orient_tile", "ccl_*", "s32_*", "no_table_cache",
+ * "uncap", "crop_ablate" (csrc/ctx.hip lists them with their ranges); an unknown name or a value out of range is PB3D_EINVAL.  Initial
+ * values come from the environment, read ONCE in pb3d_create: PB3D_KNOBS="name=value,name=value" (any knob), and PB3D_SLICED,
+ * PB3D_ROT90_WIDE, PB3D_S32_GPW, PB3D_UNCAP. */
 int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value);
 int pb3d_dev_alloc(pb3d_ctx* ctx, size_t bytes, void** dptr);
 int pb3d_dev_free(pb3d_ctx* ctx, void* dptr);

@@ -146,7 +146,7 @@ int pb3d_points_count(pb3d_ctx* ctx, const uint8_t* grid, int64_t A0, int64_t A1
     ctx->pts.extracted = false;
     // (measured on MI355X the look-back costs more than the second read of the grid saves -- 4.1 ms against 2.4 ms at 1024^3, flag round
     //  trips between XCDs are microseconds -- so the two-pass protocol stays the default; tune misc2 = 3 selects the one-pass form)
-    if (ctx->tune_misc[2] == 3 && stride == 1 && nvox > 0 && (C == 3 || ncolors == 0) && (size_t)nvox * (12 + (size_t)C) <= ((size_t)8 << 30)) {
+    if (ctx->tune_points_onepass == 1 && stride == 1 && nvox > 0 && (C == 3 || ncolors == 0) && (size_t)nvox * (12 + (size_t)C) <= ((size_t)8 << 30)) {
         void *dp, *dc;
         PB3D_TRY(pb3d_scratch(ctx, 1, (size_t)nvox * 3 * sizeof(float), &dp));
         PB3D_TRY(pb3d_scratch(ctx, 3, (size_t)nvox * C, &dc));

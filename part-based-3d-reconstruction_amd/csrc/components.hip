@@ -227,74 +227,68 @@ __global__ __launch_bounds__(256) void k_extrude_z(const u8* src, u8* dst, const
 
 // extrude_from_surface, axis 0 (reference :230-240): columns run along x for every (y,z); valid is indexed
 // [y, z] exactly as upstream indexes its (H,W) mask with the z coordinate (which needs D == W).
-// A wavefront takes 64 consecutive (y,z) columns; for every one of them that is under the mask ALL its lanes scan the column, 64 x
-// positions at a time (a plane apart each: 64 independent loads in flight, first hit by ballot).  One thread per column walked its
-// x positions as a chain of dependent loads, and the columns under a door / window mask that hold no voxel at all walk the whole
-// axis: 65 us per call at Taj 512, as much as the four calls' useful traffic takes at the HBM peak.
-__global__ __launch_bounds__(256) void k_extrude_x(const u8* src, u8* dst, const u8* __restrict__ valid_hw,
+// Round 4: one workgroup (8 waves) per 64 consecutive (y,z) columns, LANES ALONG z -- the voxels a wave reads at one x are neighbours in
+// memory (192 bytes for 64 lanes) -- and the x axis scanned in rounds of doubling length, every round split over the waves; a wave lowers
+// the column's first-hit index in LDS.  (Rounds 2-3
+// scanned a column with the 64 lanes of a wave along x, a plane apart each: every 3-byte load its own 64-byte sector, 20x the traffic,
+// 59 us per call at Taj 512; a lane per column walking x alone is a chain of W / 8 dependent round trips.)
+// (src and dst may be the same volume: a column is scanned by its workgroup before that workgroup paints it, columns are independent)
+typedef u32 u32_una __attribute__((aligned(1)));
+constexpr int kExtrudeWaves = 8;
+__global__ __launch_bounds__(64 * kExtrudeWaves) void k_extrude_x(const u8* src, u8* dst, const u8* __restrict__ valid_hw,
                                                    i64 W, i64 H, i64 D, i64 Wmask, int plus, int depth, int has_color, u8 cr, u8 cg,
                                                    u8 cb, int C) {
-    const int lane = threadIdx.x & 63;
+    __shared__ int best[64];                                   // per column: the smallest scan index with a voxel found so far
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const i64 n = H * D;
-    const i64 nchunks = (n + 63) / 64;
-    for (i64 ch = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunks; ch += (i64)gridDim.x * 4) {
-        const i64 mine = ch * 64 + lane;
-        bool v = false;
-        if (mine < n) { const i64 y = mine / D, z = mine - y * D; v = valid_hw[y * Wmask + z] != 0; }
-        u64 todo = __ballot(v);
-        if (__popcll(todo) > 12) {
-            // a DENSE mask (most of the 64 columns are under it): one lane per column, eight planes of the scan in flight -- taking the
-            // columns one by one with the whole wave would serialise 64 scans (7.7 ms instead of 1.2 at 1024^3 under an all-ones mask)
-            if (v) {
-                const i64 y = mine / D, z = mine - y * D;
-                i64 start = plus ? 0 : W - 1;
-                for (i64 j0 = 0; j0 < W; j0 += 8) {
-                    u32 on[8];
+    const i64 mine = (i64)blockIdx.x * 64 + lane;
+    bool v = false;
+    i64 y = 0, z = 0;
+    if (mine < n) { y = mine / D; z = mine - y * D; v = valid_hw[y * Wmask + z] != 0; }
+    if (!__ballot(v)) return;                                  // (every wave of the workgroup sees the same 64 columns: uniform)
+    if (wv == 0) best[lane] = 0x7fffffff;
+    __syncthreads();
+    const i64 last_vox = W * H * D - 1;
+    // rounds of 16, 32, 64, ... planes of the scan order, each split evenly over the waves: a surface right behind the boundary (a dense
+    // mask over a full grid) costs one round of two planes per wave, a column that holds nothing log2(W / 16) rounds -- at most twice the
+    // planes a lone walker would read, with up to 16 of them in flight per lane
+    for (i64 R = 0, len = 16; R < W; R += len, len *= 2) {
+        const i64 per = (len + kExtrudeWaves - 1) / kExtrudeWaves;
+        const i64 rend = R + len < W ? R + len : W;
+        const i64 a = R + wv * per, b = a + per < rend ? a + per : rend;
+        if (v && __hip_atomic_load(&best[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (int)a) {
+            for (i64 jb = a; jb < b; jb += 16) {
+                u32 on[16];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const i64 j = j0 + k < W ? j0 + k : W - 1;
-                        const i64 x = plus ? j : W - 1 - j;
-                        const u8* p = src + ((x * H + y) * D + z) * C;
-                        on[k] = C == 1 ? (u32)p[0] : ((u32)p[0] | (u32)p[1] | (u32)p[2]);
-                    }
-                    int hit = -1;
+                for (int k = 0; k < 16; ++k) {
+                    on[k] = 0u;
+                    if (jb + k >= b) continue;                                                // (wave-uniform: a round's share may be 2, 4, 8 planes)
+                    const i64 j = jb + k;
+                    const i64 x = plus ? j : W - 1 - j;
+                    const i64 vox = (x * H + y) * D + z;
+                    const u8* p = src + vox * C;
+                    if (C == 1) on[k] = p[0];
+                    else if (vox != last_vox) on[k] = *(const u32_una*)p & 0x00ffffffu;       // the voxel's three bytes in one load (the 4th byte exists)
+                    else on[k] = (u32)p[0] | (u32)p[1] | (u32)p[2];
+                }
+                int h = -1;
 #pragma unroll
-                    for (int k = 7; k >= 0; --k)
-                        if (on[k] && j0 + k < W) hit = k;
-                    if (hit >= 0) { const i64 j = j0 + hit; start = plus ? j : W - 1 - j; break; }
-                }
-                for (int d = 0; d < depth; ++d) {
-                    const i64 x = plus ? start + d : start - d;
-                    if (x < 0 || x >= W) continue;
-                    u8* o = dst + ((x * H + y) * D + z) * C;
-                    o[0] = has_color ? cr : (u8)0;
-                    if (C == 3) { o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0; }
-                }
-            }
-            continue;
-        }
-        while (todo) {
-            const int k = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const i64 i = ch * 64 + k;
-            const i64 y = i / D, z = i - y * D;
-            i64 start = plus ? 0 : W - 1;
-            for (i64 j0 = 0; j0 < W; j0 += 64) {
-                const i64 j = j0 + lane;
-                const i64 x = plus ? j : W - 1 - j;
-                bool on = false;
-                if (j < W) { const u8* p = src + ((x * H + y) * D + z) * C; on = C == 1 ? p[0] != 0 : (p[0] | p[1] | p[2]) != 0; }
-                const u64 bal = __ballot(on);
-                if (bal) { const i64 jj = j0 + (__ffsll((unsigned long long)bal) - 1); start = plus ? jj : W - 1 - jj; break; }
-            }
-            for (int d = lane; d < depth; d += 64) {
-                const i64 x = plus ? start + d : start - d;
-                if (x < 0 || x >= W) continue;
-                u8* o = dst + ((x * H + y) * D + z) * C;
-                o[0] = has_color ? cr : (u8)0;
-                if (C == 3) { o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0; }
+                for (int k = 15; k >= 0; --k)
+                    if (on[k]) h = k;
+                if (h >= 0) { atomicMin(&best[lane], (int)(jb + h)); break; }
             }
         }
+        if (!__syncthreads_or(v && best[lane] == 0x7fffffff)) break;       // every column under the mask has its surface
+    }
+    if (!v) return;
+    const int f = best[lane];
+    const i64 start = f == 0x7fffffff ? (plus ? 0 : W - 1) : (plus ? (i64)f : W - 1 - (i64)f);   // argmax of an all-zero column is index 0 (of the possibly reversed view)
+    for (int d = wv; d < depth; d += kExtrudeWaves) {
+        const i64 x = plus ? start + d : start - d;
+        if (x < 0 || x >= W) continue;
+        u8* o = dst + ((x * H + y) * D + z) * C;
+        o[0] = has_color ? cr : (u8)0;
+        if (C == 3) { o[1] = has_color ? cg : (u8)0; o[2] = has_color ? cb : (u8)0; }
     }
 }
 
@@ -603,7 +597,7 @@ int pb3d_orient_dev(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int64_t
     if (W * H * D == 0) return PB3D_OK;
     PB3D_REQUIRE(d_grid_rgb && d_out && d_grid_rgb != d_out, "pb3d_orient: null or aliased buffer");
     PB3D_REQUIRE(H <= 65535 && (D + 31) / 32 <= 65535, "pb3d_orient: grid too large");
-    if (W % kOT == 0 && D % kOT == 0 && ((((uintptr_t)d_grid_rgb) | ((uintptr_t)d_out)) & 15u) == 0 && ctx->tune_misc[2] != 5) {
+    if (W % kOT == 0 && D % kOT == 0 && ((((uintptr_t)d_grid_rgb) | ((uintptr_t)d_out)) & 15u) == 0 && ctx->tune_orient_tile != 1) {
         if (!ctx->orient_lds_set) {
             PB3D_HIP(hipFuncSetAttribute((const void*)k_orient128, hipFuncAttributeMaxDynamicSharedMemorySize, kOT * kOPitch));
             ctx->orient_lds_set = true;
@@ -637,7 +631,8 @@ static int extrude_impl(pb3d_ctx* ctx, const uint8_t* d_grid_rgb, int64_t W, int
                            plus ? 1 : 0, depth, fill_color ? 1 : 0, cr, cg, cb, C);
     } else {
         PB3D_REQUIRE(valid_w >= D, "pb3d_extrude: axis-0 extrusion indexes the (H,W) mask with z and needs W_mask >= D");
-        hipLaunchKernelGGL(k_extrude_x, dim3(pb3d_stream_blocks(ctx, (H * D + 63) / 64, 4, 8)), dim3(256), 0, ctx->stream, d_grid_rgb, d_out, d_valid, W,
+        PB3D_REQUIRE((H * D + 63) / 64 < (1ll << 31), "pb3d_extrude: grid too large");
+        hipLaunchKernelGGL(k_extrude_x, dim3((unsigned)((H * D + 63) / 64)), dim3(64 * kExtrudeWaves), 0, ctx->stream, d_grid_rgb, d_out, d_valid, W,
                            H, D, valid_w, plus ? 1 : 0, depth, fill_color ? 1 : 0, cr, cg, cb, C);
     }
     PB3D_CHECK_LAUNCH();

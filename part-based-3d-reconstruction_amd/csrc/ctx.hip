@@ -2,6 +2,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <string>
+
 #include "pb3d_internal.h"
 
 static int pool_flush(pb3d_ctx* ctx);
@@ -55,8 +57,6 @@ int pb3d_create(int device, pb3d_ctx** out) {
     ctx->device = device;
     {
         auto env_int = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; };
-        const char* names[6] = {"PB3D_TUNE0", "PB3D_TUNE1", "PB3D_TUNE2", "PB3D_TUNE3", "PB3D_TUNE4", "PB3D_TUNE5"};
-        for (int i = 0; i < 6; ++i) ctx->tune_misc[i] = env_int(names[i]);
         ctx->tune_uncap = env_int("PB3D_UNCAP");
         ctx->tune_sliced = env_int("PB3D_SLICED");
         ctx->tune_s32_gpw = env_int("PB3D_S32_GPW");
@@ -95,48 +95,68 @@ int pb3d_create(int device, pb3d_ctx** out) {
         pb3d_set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
         return PB3D_ENOMEM;
     }
+    // PB3D_KNOBS="name=value,name=value": development knobs by name (pb3d_set_tuning), read once here; an unknown name or a value out of
+    // range fails the creation loudly rather than silently measuring the wrong kernel
+    if (const char* kn = getenv("PB3D_KNOBS")) {
+        std::string all(kn);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            const size_t end = all.find(',', pos);
+            const std::string item = all.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+            pos = end == std::string::npos ? all.size() : end + 1;
+            if (item.empty()) continue;
+            const size_t eq = item.find('=');
+            const int rc = eq == std::string::npos ? PB3D_EINVAL : pb3d_set_tuning(ctx, item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1));
+            if (rc != PB3D_OK) {
+                if (eq == std::string::npos) pb3d_set_error("PB3D_KNOBS: '%s' is not name=value", item.c_str());
+                (void)hipHostFree(ctx->pinned);
+                (void)hipStreamDestroy(ctx->stream);
+                free(ctx);
+                return PB3D_EINVAL;
+            }
+        }
+    }
     *out = ctx;
     return PB3D_OK;
 }
 
+namespace {
+struct Knob { const char* name; int pb3d_ctx::*field; int lo, hi; const char* what; };
+const Knob kKnobs[] = {
+    {"sliced", &pb3d_ctx::tune_sliced, 0, 1, "0 (rotation steps on 0/1 data run bit-sliced) or 1 (never: byte chain)"},
+    {"rot90_wide", &pb3d_ctx::tune_rot90_wide, 0, 2, "0 (choose), 1 or 2 (the 128-tile / 128-byte-segment kernels)"},
+    {"rot90_fill", &pb3d_ctx::tune_rot90_fill, 0, 64, "a count of workgroups per CU (0 = the built-in rule)"},
+    {"rot90_order", &pb3d_ctx::tune_rot90_order, 0, 1, "0 (a plane chunk per XCD) or 1 (plain x-fastest order)"},
+    {"rot90_flat", &pb3d_ctx::tune_rot90_flat, 0, 2, "0 (choose), 1 (row-wise tile kernel) or 2 (flat on whole-line streams only)"},
+    {"rot90_mask_block", &pb3d_ctx::tune_rot90_mask_block, 0, 1, "0 (mask bytes once into LDS) or 1 (per plane / segment)"},
+    {"s32_gpw", &pb3d_ctx::tune_s32_gpw, 0, 1 << 20, "a count of plane groups"},
+    {"s32_order", &pb3d_ctx::tune_s32_order, 0, 1, "0 (plane groups fastest) or 1 (x fastest)"},
+    {"s32_fuse_last", &pb3d_ctx::tune_s32_fuse_last, 0, 1, "0 (fused) or 1 (table step)"},
+    {"ccl_blocks", &pb3d_ctx::tune_ccl_blocks, 0, 1 << 20, "a count of workgroups per CU"},
+    {"ccl_init_blocks", &pb3d_ctx::tune_ccl_init_blocks, 0, 1 << 20, "a count of workgroups per CU"},
+    {"ccl_tilecols", &pb3d_ctx::tune_ccl_tilecols, 0, 64, "at most 64"},
+    {"ccl_merge", &pb3d_ctx::tune_ccl_merge, 0, 1, "0 (tile kernels) or 1 (pairwise kernel)"},
+    {"points_fill", &pb3d_ctx::tune_points_fill, 0, 1, "0 (wave-private fill) or 1 (block form)"},
+    {"points_onepass", &pb3d_ctx::tune_points_onepass, 0, 1, "0 (count + fill) or 1 (one-pass look-back form in the host entry)"},
+    {"orient_tile", &pb3d_ctx::tune_orient_tile, 0, 1, "0 (128-pixel tiles where they apply) or 1 (never)"},
+    {"global_composed", &pb3d_ctx::tune_global_composed, 0, 1, "0 (mask bits -> sliced chain -> colours) or 1 (ones -> process -> colour)"},
+    {"per_job", &pb3d_ctx::tune_per_job, 0, 1, "0 (merged / fused forms) or 1 (job by job)"},
+    {"no_table_cache", &pb3d_ctx::tune_no_table_cache, 0, 1, "0 (tables cached across calls) or 1 (rebuilt every call)"},
+    {"crop_ablate", &pb3d_ctx::tune_crop_ablate, 0, 1 << 20, "ablation switches of k_crop_chain"},
+    {"uncap", &pb3d_ctx::tune_uncap, 0, 1, "0 or 1 (every grid-stride kernel as one workgroup per tile)"},
+};
+}  // namespace
+
 int pb3d_set_tuning(pb3d_ctx* ctx, const char* name, int value) {
     PB3D_REQUIRE(ctx != nullptr && name != nullptr, "pb3d_set_tuning: null argument");
-    if (!strcmp(name, "sliced")) {
-        PB3D_REQUIRE(value >= 0 && value <= 1, "pb3d_set_tuning: sliced is 0 (rotation steps on 0/1 data run bit-sliced) or 1 (never: byte chain)");
-        ctx->tune_sliced = value;
-    } else if (!strcmp(name, "rot90_wide")) {
-        ctx->tune_rot90_wide = value;
-    } else if (!strcmp(name, "s32_gpw")) {
-        PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: s32_gpw is a count of plane groups");
-        ctx->tune_s32_gpw = value;
-    } else if (!strcmp(name, "ccl_blocks")) {
-        PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: ccl_blocks is a count of workgroups per CU");
-        ctx->tune_ccl_blocks = value;
-    } else if (!strcmp(name, "s32_order")) {
-        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: s32_order is 0 (plane groups fastest) or 1 (x fastest)");
-        ctx->tune_s32_order = value;
-    } else if (!strcmp(name, "s32_fuse_last")) {
-        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: s32_fuse_last is 0 (fused) or 1 (table step)");
-        ctx->tune_s32_fuse_last = value;
-    } else if (!strcmp(name, "ccl_init_blocks")) {
-        PB3D_REQUIRE(value >= 0, "pb3d_set_tuning: ccl_init_blocks is a count of workgroups per CU");
-        ctx->tune_ccl_init_blocks = value;
-    } else if (!strcmp(name, "ccl_tilecols")) {
-        PB3D_REQUIRE(value >= 0 && value <= 64, "pb3d_set_tuning: ccl_tilecols is at most 64");
-        ctx->tune_ccl_tilecols = value;
-    } else if (!strcmp(name, "points_fill")) {
-        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: points_fill is 0 (wave-private fill) or 1 (block form)");
-        ctx->tune_points_fill = value;
-    } else if (!strcmp(name, "ccl_merge")) {
-        PB3D_REQUIRE(value == 0 || value == 1, "pb3d_set_tuning: ccl_merge is 0 (tile kernels) or 1 (pairwise kernel)");
-        ctx->tune_ccl_merge = value;
-    } else if (!strncmp(name, "misc", 4) && name[4] >= '0' && name[4] <= '5' && !name[5]) {
-        ctx->tune_misc[name[4] - '0'] = value;
-    } else {
-        pb3d_set_error("pb3d_set_tuning: unknown knob '%s'", name);
-        return PB3D_EINVAL;
-    }
-    return PB3D_OK;
+    for (const Knob& k : kKnobs)
+        if (!strcmp(name, k.name)) {
+            PB3D_REQUIRE(value >= k.lo && value <= k.hi, "pb3d_set_tuning: %s is %s (got %d)", k.name, k.what, value);
+            ctx->*k.field = value;
+            return PB3D_OK;
+        }
+    pb3d_set_error("pb3d_set_tuning: unknown knob '%s'", name);
+    return PB3D_EINVAL;
 }
 
 int pb3d_make_current(pb3d_ctx* ctx) {

@@ -35,7 +35,7 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     PB3D_REQUIRE(d_bin_hw && d_rgb_hw3 && d_out_slab, "pb3d_global_carve: null buffer");
     const i64 shape[3] = {W, H, D};
     if (angle_interval == 90) {
-        // angles [0, 90]: both steps are exact permutations on a (w,h,w) grid -> one write-only kernel (k_global_carve90s, csrc/carve.hip)
+        // angles [0, 90]: both steps are exact permutations on a (w,h,w) grid -> one write-only kernel (k_global_carve90s, csrc/bits90.hip)
         double M[9], off[3];
         PB3D_TRY(pb3d_rotinv(90, M));
         PB3D_TRY(pb3d_offset(M, shape, off));
@@ -49,7 +49,7 @@ int pb3d_global_carve_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const uint8_t*
     void* mwh;
     PB3D_TRY(pb3d_scratch(ctx, 7, (size_t)(W * H), &mwh));
     PB3D_TRY(pb3d_transpose_mask_dev(ctx, d_bin_hw, H, W, (u8*)mwh));
-    if (nsteps >= 2 && ctx->tune_misc[3] != 1) {                    // tune misc3 = 1: the composed pipeline (parity tests run both)
+    if (nsteps >= 2 && ctx->tune_global_composed != 1) {             // knob global_composed = 1: the composed pipeline (parity tests run both)
         int took = 0;
         PB3D_TRY(pb3d_global_carve_sliced(ctx, (const u8*)mwh, d_rgb_hw3, W, H, D, angle_interval, d_out_slab, &took));
         if (took) return PB3D_OK;

@@ -342,7 +342,7 @@ static int guided_carve_impl(pb3d_ctx* ctx, uint8_t* d_grid_rgb, const int32_t* 
             hipLaunchKernelGGL(k_crop_slice, dim3((unsigned)((maxcells + 255) / 256), (unsigned)g0), dim3(256), 0, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), H, D,
                                (const CropDesc*)ddb, n, (u32*)dsl, C, W * H * D);
             hipLaunchKernelGGL(k_crop_chain, dim3((unsigned)g0), dim3(GTHREADS), lds_max, ctx->stream, (const u8*)(copy ? copy : d_grid_rgb), d_grid_rgb,
-                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_misc[0] >= 100 ? ctx->tune_misc[0] - 100 : 0, (const u32*)dsl, mb64, mbP);
+                               d_labels, H, D, (const CropDesc*)ddb, n, (const u8*)d_masks, (const u32*)dt, nrot, (unsigned long long*)d_counts, copy ? 1 : 0, C, W * H * D, ctx->tune_crop_ablate, (const u32*)dsl, mb64, mbP);
             PB3D_CHECK_LAUNCH();
         }
         static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counts are 64-bit");

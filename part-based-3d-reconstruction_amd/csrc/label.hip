@@ -312,7 +312,7 @@ int pb3d_global_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_bin_hw, const ui
     const i64 W = w, H = h, D = w, nvox = W * H * D;
     if (nvox == 0) return PB3D_OK;
     PB3D_REQUIRE(d_bin_hw && d_label_hw && d_out, "pb3d_global_carve_label: null buffer");
-    if (angle_interval == 90 && ctx->tune_misc[3] != 2) {       // the write-only stream kernel of the RGB form on label bytes (csrc/carve.hip, k_global_carve90s<., 1>)
+    if (angle_interval == 90 && ctx->tune_per_job != 1) {       // the write-only stream kernel of the RGB form on label bytes (csrc/bits90.hip, k_global_carve90s<., 1>)
         const i64 shape[3] = {W, H, D};
         double M[9], off[3];
         PB3D_TRY(pb3d_rotinv(90, M));
@@ -349,13 +349,13 @@ int pb3d_part_carve_label_dev(pb3d_ctx* ctx, const uint8_t* d_label, int64_t W, 
                  "pb3d_part_carve_label: null or aliased buffer");
     for (int j = 0; j < njobs; ++j)
         PB3D_REQUIRE(job_skip[j] || job_angle[j] > 0, "pb3d_part_carve_label: job %d has angle %d (must be > 0)", j, job_angle[j]);
-    // all live jobs at 90 degrees (the notebook's group_jobs): ONE launch of the plane-local kernel on the label bytes (csrc/carve.hip,
+    // all live jobs at 90 degrees (the notebook's group_jobs): ONE launch of the plane-local kernel on the label bytes (csrc/bits90.hip,
     // k_part90_plane<1>: occupancy = label != 0) instead of occupancy / process / keep passes per job
     {
         bool all90 = njobs > 0 && njobs <= 32, any_live = false;
         for (int j = 0; j < njobs; ++j)
             if (!job_skip[j]) { any_live = true; all90 = all90 && job_angle[j] == 90; }
-        if (all90 && any_live && ctx->tune_misc[3] != 2) {
+        if (all90 && any_live && ctx->tune_per_job != 1) {
             const int rc = pb3d_try_part_carve90(ctx, d_label, 1, W, H, D, d_mask_sub, d_mask_carve, job_angle, job_skip, njobs, d_out);
             if (rc != PB3D_EUNSUPPORTED) return rc;
         }

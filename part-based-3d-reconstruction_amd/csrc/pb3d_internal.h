@@ -29,7 +29,17 @@ struct pb3d_ctx {
     bool orient_lds_set;        // ... and for the 128-pixel orientation kernel (csrc/components.hip)
     bool guided_lds_set;        // ... and for the crop-chain kernel of left_right_guided_carve (csrc/guided.hip)
     // development knobs, read from the environment ONCE in pb3d_create (never on a launch path)
-    int tune_misc[6];           // PB3D_TUNE0..5: experiment switches of kernels under development
+    // (round 4: every knob has a name -- the numbered "misc" switches of rounds 1-3 are gone; PB3D_KNOBS="name=value,..." sets any of them at pb3d_create)
+    int tune_rot90_fill;        // knob "rot90_fill": workgroups per CU in the grid of the 90-degree kernels (0 = the built-in rule)
+    int tune_rot90_order;       // knob "rot90_order": 1 = tiles in plain x-fastest order instead of one plane chunk per XCD
+    int tune_rot90_flat;        // knob "rot90_flat": 0 = choose, 1 = never the flat (stream) forms: the row-wise tile kernel, 2 = flat only on whole-line streams
+    int tune_rot90_mask_block;  // knob "rot90_mask_block": 1 = the 90-degree kernels fetch their mask bytes per plane / segment instead of once into LDS
+    int tune_points_onepass;    // knob "points_onepass": 1 = the host entry of the point extraction uses the one-pass (look-back) form
+    int tune_orient_tile;       // knob "orient_tile": 1 = pb3d_orient_dev without its 128-pixel tile kernel
+    int tune_global_composed;   // knob "global_composed": 1 = global_carve with other angle steps as ones -> process -> colour (parity tests run both)
+    int tune_per_job;           // knob "per_job": 1 = part_carve's non-90 jobs one by one (no merged pass); label forms of global_carve / part_carve by their per-job passes
+    int tune_no_table_cache;    // knob "no_table_cache": 1 = validity tables and tile programs are rebuilt on every call
+    int tune_crop_ablate;       // knob "crop_ablate": ablation switches of k_crop_chain (tools/cropabl.py)
     int tune_uncap;             // PB3D_UNCAP=1: every grid-stride kernel gets one workgroup per tile (A/B of the persistent grids)
     int tune_sliced;            // PB3D_SLICED: 0 = rotation steps on 0/1 data run bit-sliced (csrc/sliced.hip), 1 = never (byte chain, arithmetic kernel)
     int tune_rot90_wide;        // PB3D_ROT90_WIDE: 1 = the 256 x 256-tile form of the 90-degree step (development A/B)

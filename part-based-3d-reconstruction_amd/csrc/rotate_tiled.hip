@@ -190,7 +190,7 @@ typedef u32x4 u32x4_u __attribute__((aligned(1)));     // 16-byte access at any 
 typedef u32 u32_u __attribute__((aligned(1)));
 
 // (K4, global_carve(binary, rgb, 90): the per-row piece kernels k_global_carve90v / 90f of rounds 1-3 are gone -- the stream kernel
-// k_global_carve90s in csrc/carve.hip is faster on every shape, profiles/r04_global_carve90_stream_vs_piece_kernels.jsonl.)
+// k_global_carve90s in csrc/bits90.hip is faster on every shape, profiles/r04_global_carve90_stream_vs_piece_kernels.jsonl.)
 
 // ------------------------------------------------------------------------------------------------
 // K2' fast form for the 90-degree map n0 = c0 - z, n2 = x + c2.  Any W, H, D and any pointer alignment: gfx950 serves
@@ -869,11 +869,11 @@ __global__ __launch_bounds__(1024) void k_rot90wf(const u8* __restrict__ in, u8*
 //   keep[x,y,z] = valid(x,z) && occ[c0 - z, y, x + c2] && (A[x,y] & A[c0 - z, y]) != 0
 // with occ = any(colored > 0) and A[x,y] = bitset over jobs of (mask_sub_j && mask_carve_j)[x,y]
 // (both the source-side and the destination-side carve of a job use its own masks).
-// The sweep itself is k_part90_plane in csrc/carve.hip (round 4: occupancy BITS of a plane transposed, whole output rows); the byte-tile
+// The sweep itself is k_part90_plane in csrc/bits90.hip (round 4: occupancy BITS of a plane transposed, whole output rows); the byte-tile
 // kernels k_part90 / k_part90_flat of rounds 1-3 are gone -- slower on every shape (profiles/r04_part_carve_plane_kernel_vs_tile_kernels.jsonl).
 // ------------------------------------------------------------------------------------------------
 // job_on: bit j = job j takes part (passed by value: a device copy of the flags cost a memcpy and a stream synchronisation per call)
-// AT (optional): the same sets in (y, x) order, for the plane-wise pass of the stream form (csrc/carve.hip, k_part90_keep)
+// AT (optional): the same sets in (y, x) order, for the plane-wise pass of the stream form (csrc/bits90.hip, k_part90_keep)
 __global__ __launch_bounds__(256) void k_job_bitset(const u8* __restrict__ mask_sub, const u8* __restrict__ mask_carve,
                                                     u32 job_on, int nj, i64 npix, u32* __restrict__ A, u32* __restrict__ AT, i64 W, i64 H) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (i64)gridDim.x * blockDim.x) {
@@ -932,7 +932,7 @@ static int build_valid_table(pb3d_ctx* ctx, const RotParams& p, i64 W, i64 D, u3
     // the table depends on (matrix, offset, W, D) only and slot 10 is private to it: a repeated step (every 90-degree call on one shape)
     // finds it in place -- at 512-class sizes the memset + table kernel were 10 % of a process_voxel_grid(., ., 90) call
     pb3d_ctx::ValidCache& vc = ctx->valid_cache;
-    if (vc.buf == buf && vc.gen == ctx->scratch_gen && vc.W == W && vc.D == D && memcmp(vc.p, &p, sizeof(RotParams)) == 0 && ctx->tune_misc[4] != 1) {
+    if (vc.buf == buf && vc.gen == ctx->scratch_gen && vc.W == W && vc.D == D && memcmp(vc.p, &p, sizeof(RotParams)) == 0 && ctx->tune_no_table_cache != 1) {
         *bits = (u32*)buf; *nw = n;
         return PB3D_OK;
     }
@@ -971,14 +971,14 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
         // rows that are not whole lines: the stream of each x-row tiled in whole lines (k_rot90_flat / k_rot90wf) -- streams that are whole lines
         // (H * D % 128 == 0: every real shape of the reference whose longer mask side is the height) or at least whole 16-byte pieces
         // (H * D % 16 == 0, e.g. 500 x 400 x 500: the last segment of an x-row's stream is ragged, the rows of odd x start mid-line);
-        // tune misc2: 2 = the row-wise tile kernel instead, 4 = whole-line streams only
-        const bool lines_ok = D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_misc[2] != 2;
-        const bool flat16 = D % 128 != 0 && (H * D) % 16 == 0 && D >= 128 && ctx->tune_misc[2] != 2 && ctx->tune_misc[2] != 4;
+        // knob rot90_flat: 1 = the row-wise tile kernel instead, 2 = whole-line streams only
+        const bool lines_ok = D % 128 != 0 && (H * D) % 128 == 0 && D >= 128 && ctx->tune_rot90_flat != 1;
+        const bool flat16 = D % 128 != 0 && (H * D) % 16 == 0 && D >= 128 && ctx->tune_rot90_flat == 0;
         const bool flat = (lines_ok || flat16) && H * D < (1ll << 31) - 256 && (((uintptr_t)d_out) & 127u) == 0;
         const i64 nzt = (D + 127) / 128;
         const i64 tiles = nzt * ((W + 127) / 128);
-        const int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_misc[1]);
-        const TileMap tm = {(int)nzt, (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_misc[2] == 1 ? 1 : 0};
+        const int TY = planes_per_chunk(H, tiles, ctx->cus, 32, ctx->tune_rot90_fill);
+        const TileMap tm = {(int)nzt, (int)((W + 127) / 128), (int)((H + TY - 1) / TY), ctx->tune_rot90_order == 1 ? 1 : 0};
         dim3 grid(tilemap_blocks(tm));
 #ifndef PB3D_ROT90_DEPTH
 #define PB3D_ROT90_DEPTH 1
@@ -993,21 +993,21 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
             const int npc = (int)((((W + nx0 - 1) / nx0) + 15) / 16);          // 16-byte blocks of a tile's source rows (10 .. 16)
             const i64 nseg = (H * D + 255) / 256, nxt = (W + 16 * npc - 1) / (16 * npc);
             // workgroups per CU: as many (up to 4) as leave a workgroup at least 8 segments (fewer, longer workgroups win at these sizes)
-            int fillw = ctx->tune_misc[1] > 0 ? ctx->tune_misc[1] : 4;
-            if (ctx->tune_misc[1] <= 0)
+            int fillw = ctx->tune_rot90_fill > 0 ? ctx->tune_rot90_fill : 4;
+            if (ctx->tune_rot90_fill <= 0)
                 while (fillw > 1 && planes_per_chunk(nseg, nxt, ctx->cus, 32, fillw) < 8) fillw >>= 1;
             const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, fillw);
             const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), 0};
             // the workgroup's mask block behind the tile: (W + XW) rows x 8 planes per window, windows for the planes TS segments span
             const i64 nwin = ((i64)TS * 256 / D + 2) / 8 + 1;
             const size_t blk_bytes = (size_t)((W + 16 * npc) * 8 * nwin);
-            const int blk_on = blk_bytes <= 48 * 1024 && ctx->tune_misc[5] != 16;
+            const int blk_on = blk_bytes <= 48 * 1024 && ctx->tune_rot90_mask_block != 1;
             hipLaunchKernelGGL(k_rot90wf, dim3(tilemap_blocks(fm)), dim3(1024), 256 * 256 + (blk_on ? blk_bytes : 0), ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, (const u32*)bits + W * nw, nw, pm.c0, pm.c2, W, H, D, TS, fm, pb3d_make_magic((u32)D), nseg, npc, blk_on);
         } else if (flat) {
             const i64 nseg = (H * D + 127) / 128, nxt = (W + 127) / 128;
-            const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_misc[1]);
-            const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_misc[2] == 1 ? 1 : 0};
+            const int TS = planes_per_chunk(nseg, nxt, ctx->cus, 32, ctx->tune_rot90_fill);
+            const TileMap fm = {1, (int)nxt, (int)((nseg + TS - 1) / TS), ctx->tune_rot90_order == 1 ? 1 : 0};
             hipLaunchKernelGGL(k_rot90_flat, dim3(tilemap_blocks(fm)), dim3(256), 0, ctx->stream, d_in, d_out, d_mask_src, d_mask_dst, (const u32*)bits, nw,
                                pm.c0, pm.c2, W, H, D, TS, fm, pb3d_make_magic((u32)D), nseg);
         } else if (D % 16 == 0 && pm.c2 % 16 == 0 && W >= 256 && D >= 256 && ctx->tune_rot90_wide != 2 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0) {
@@ -1021,12 +1021,12 @@ int pb3d_launch_rotate_perm(pb3d_ctx* ctx, const u8* d_in, i64 W, i64 H, i64 D, 
                 ctx->rot90w_lds_set = true;
             }
             const i64 wt = ((D + 255) / 256) * ((W + 255) / 256);
-            int fillw = ctx->tune_misc[1] > 0 ? ctx->tune_misc[1] : 8;
-            if (ctx->tune_misc[1] <= 0)
+            int fillw = ctx->tune_rot90_fill > 0 ? ctx->tune_rot90_fill : 8;
+            if (ctx->tune_rot90_fill <= 0)
                 while (fillw > 1 && planes_per_chunk(H, wt, ctx->cus, 32, fillw) < 4) fillw >>= 1;
             const int TYw = planes_per_chunk(H, wt, ctx->cus, 32, fillw);
             const TileMap wm = {(int)((D + 255) / 256), (int)((W + 255) / 256), (int)((H + TYw - 1) / TYw), 0};
-            const int blk_on = TYw <= 64 && ctx->tune_misc[5] != 16;                 // the workgroup's mask flags behind the tile: 512 bytes per plane
+            const int blk_on = TYw <= 64 && ctx->tune_rot90_mask_block != 1;                 // the workgroup's mask flags behind the tile: 512 bytes per plane
             hipLaunchKernelGGL(k_rot90w, dim3(tilemap_blocks(wm)), dim3(1024), 256 * 256 + (blk_on ? 512 * TYw : 0), ctx->stream, d_in, d_out, d_mask_src, d_mask_dst,
                                (const u32*)bits, nw, pm.c0, pm.c2, W, H, D, TYw, wm, blk_on);
         } else if (D % 16 == 0 && pm.c2 % 16 == 0)

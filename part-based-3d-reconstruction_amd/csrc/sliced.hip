@@ -670,7 +670,7 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
             void* tp;
             PB3D_TRY(pb3d_scratch(ctx, 32, (size_t)ns * ntiles * sizeof(STile), &tp));
             pb3d_ctx::S32Cache& sc = ctx->s32_cache;
-            const bool hit = ctx->tune_misc[4] != 1 && sc.valid && sc.gen == ctx->scratch_gen && sc.W == W && sc.D == D && sc.ns == ns &&
+            const bool hit = ctx->tune_no_table_cache != 1 && sc.valid && sc.gen == ctx->scratch_gen && sc.W == W && sc.D == D && sc.ns == ns &&
                              memcmp(sc.p, sp.p, sizeof(RotParams) * (size_t)ns) == 0;
             if (!hit) {
                 sc.valid = false;

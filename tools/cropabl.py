@@ -16,7 +16,7 @@ for part, ang in (("dome", 5), ("front_minarets", 5), ("chhatris", 45)):
     mask2d = V._is_color(sm, key, PCN[part])
     row = {"part": part}
     for abl in (0, 1, 2, 4, 7):
-        pb3d._lib.set_tuning("misc0", 100 + abl if abl else 0)
+        pb3d._lib.set_tuning("crop_ablate", abl)
         ts = []
         for r in range(4):
             d_w = dev.DeviceBuffer(W * H * D * 3)
@@ -27,5 +27,5 @@ for part, ang in (("dome", 5), ("front_minarets", 5), ("chhatris", 45)):
             dev.sync(); ts.append(time.perf_counter() - t0)
             d_w.free()
         row[f"abl{abl}_ms"] = round(min(ts) * 1e3, 3)
-    pb3d._lib.set_tuning("misc0", 0)
+    pb3d._lib.set_tuning("crop_ablate", 0)
     print(json.dumps(row), flush=True)

@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--ops", default="M1,M2,M3,M4,M5,M6,M7,M8,A2,A6,A9,N2")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--tune", default="", help="development knobs, e.g. misc1=6 (pb3d_set_tuning)")
+    ap.add_argument("--tune", default="", help="development knobs, e.g. rot90_fill=6 (pb3d_set_tuning)")
     a = ap.parse_args()
     for kv in [t for t in a.tune.split(',') if t]:
         pb3d._lib.set_tuning(kv.split('=')[0], int(kv.split('=')[1]))

@@ -28,7 +28,7 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="128x123x128,512x278x512,355x512x355,512x512x512,437x512x437,500x400x500")
-    ap.add_argument("--tune", default="", help="development knobs, e.g. misc2=1,sliced=1 (pb3d_set_tuning)")
+    ap.add_argument("--tune", default="", help="development knobs, e.g. rot90_flat=1,sliced=1 (pb3d_set_tuning)")
     a = ap.parse_args()
     tune = dict(kv.split("=") for kv in a.tune.split(",") if kv)
     for k, v in tune.items():

@@ -1,4 +1,4 @@
-"""Development A/B of the planes-per-workgroup rule of the 90-degree kernels: process_voxel_grid(occ, 90) under tune misc1 = fill
+"""Development A/B of the planes-per-workgroup rule of the 90-degree kernels: process_voxel_grid(occ, 90) under knob rot90_fill
 (0 = the built-in rule), variants interleaved and repeated so that clock / box drift shows up as spread instead of as a winner.
 python tools/tybench.py --shapes 1024x1024x1024,512x512x512 --fills 0,4,6,8,12 --rounds 3"""
 import argparse, json, os, sys
@@ -78,9 +78,9 @@ def main():
             for wd in a.wide.split(","):
                 pb3d._lib.set_tuning("rot90_wide", int(wd))
                 for f in a.fills.split(","):
-                    pb3d._lib.set_tuning("misc1", int(f))
+                    pb3d._lib.set_tuning("rot90_fill", int(f))
                     res.setdefault(f"tile256:{f}" if wd == "0" else f"tile128:{f}", []).append(round(timeit(lambda: dev.process_grid(d_occ, W, H, D, d_mwh, 90, d_o, d_t), a.reps), 4))
-        pb3d._lib.set_tuning("misc1", 0); pb3d._lib.set_tuning("rot90_wide", 0)
+        pb3d._lib.set_tuning("rot90_fill", 0); pb3d._lib.set_tuning("rot90_wide", 0)
         print(json.dumps({"shape": [W, H, D], "ms_by_fill": res}), flush=True)
         for b in (d_mwh, d_occ, d_o, d_t):
             b.free()
