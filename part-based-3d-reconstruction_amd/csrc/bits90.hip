@@ -350,6 +350,11 @@ int pb3d_part_carve90_planes(pb3d_ctx* ctx, const u8* d_colored, int C, i64 W, i
     // items in flight per thread in the source pass / the output pass: 2 / 4 (tools/tybench.py --op part, the nine combinations of 1, 2, 4
     // interleaved on one box: best or tied at 512 x 278 x 512, 355 x 512 x 355, 512^3 and 1024^3; profiles/r04_part_carve_plane_kernel_unroll_sweep.jsonl)
     auto kern = C == 3 ? k_part90_plane<3, 2, 4> : k_part90_plane<1, 2, 4>;
+    if (C == 3 && ctx->tune_part90_inflight) {               // development A/B: 10 UA + UE
+        const int t = ctx->tune_part90_inflight;
+        kern = t == 11 ? k_part90_plane<3, 1, 1> : t == 12 ? k_part90_plane<3, 1, 2> : t == 14 ? k_part90_plane<3, 1, 4> : t == 21 ? k_part90_plane<3, 2, 1>
+             : t == 22 ? k_part90_plane<3, 2, 2> : t == 42 ? k_part90_plane<3, 4, 2> : t == 44 ? k_part90_plane<3, 4, 4> : kern;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)((W + 127) / 128), (unsigned)H), dim3(256), lds, ctx->stream, d_colored, d_A, d_AT, d_vbits, nwv, c0, c2,
                        W, H, D, nwz, njobs, pb3d_make_magic((u32)npieces), d_out);
     PB3D_CHECK_LAUNCH();

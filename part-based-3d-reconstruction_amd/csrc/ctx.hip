@@ -142,6 +142,7 @@ const Knob kKnobs[] = {
     {"global_composed", &pb3d_ctx::tune_global_composed, 0, 1, "0 (mask bits -> sliced chain -> colours) or 1 (ones -> process -> colour)"},
     {"per_job", &pb3d_ctx::tune_per_job, 0, 1, "0 (merged / fused forms) or 1 (job by job)"},
     {"no_table_cache", &pb3d_ctx::tune_no_table_cache, 0, 1, "0 (tables cached across calls) or 1 (rebuilt every call)"},
+    {"part90_inflight", &pb3d_ctx::tune_part90_inflight, 0, 44, "10 UA + UE with UA, UE in 1, 2, 4 (0 = the default 2 / 4)"},
     {"crop_ablate", &pb3d_ctx::tune_crop_ablate, 0, 1 << 20, "ablation switches of k_crop_chain"},
     {"uncap", &pb3d_ctx::tune_uncap, 0, 1, "0 or 1 (every grid-stride kernel as one workgroup per tile)"},
 };

@@ -39,6 +39,7 @@ struct pb3d_ctx {
     int tune_global_composed;   // knob "global_composed": 1 = global_carve with other angle steps as ones -> process -> colour (parity tests run both)
     int tune_per_job;           // knob "per_job": 1 = part_carve's non-90 jobs one by one (no merged pass); label forms of global_carve / part_carve by their per-job passes
     int tune_no_table_cache;    // knob "no_table_cache": 1 = validity tables and tile programs are rebuilt on every call
+    int tune_part90_inflight;   // knob "part90_inflight": 10 UA + UE, items in flight per thread in the source / output pass of k_part90_plane (0 = 2 / 4)
     int tune_crop_ablate;       // knob "crop_ablate": ablation switches of k_crop_chain (tools/cropabl.py)
     int tune_uncap;             // PB3D_UNCAP=1: every grid-stride kernel gets one workgroup per tile (A/B of the persistent grids)
     int tune_sliced;            // PB3D_SLICED: 0 = rotation steps on 0/1 data run bit-sliced (csrc/sliced.hip), 1 = never (byte chain, arithmetic kernel)

@@ -18,4 +18,6 @@ cp $O/shapebench.jsonl $P/r04_shapebench_real_shapes.jsonl
 cp $O/tybench_part.jsonl $P/r04_tybench_part_carve.jsonl
 cp $O/notebook1.json $P/r04_notebook1_taj512_host_api.json; cp $O/nb1prof.txt $P/r04_notebook1_taj512_kernel_stats.txt
 cp $O/cclbench.jsonl $P/r04_cclbench.jsonl
-python tools/pmc_summary.py $P/r04_bench_pmc_fetch_size.csv $P/r04_bench_pmc_write_size.csv 1073741824 "r04 bench.py --steps 5, 1024^3 M1" | tail -1
+# (profiles/pmc_traffic.json: copied from gpurun_out/slabpmc_<tag>/pmc_traffic.json, made on the GPU box by tools/slab_pmc.sh with the tree that ran)
+cp gpurun_out/slabpmc_$TAG/pmc_traffic.json $P/pmc_traffic.json
+cp $O/slicedprof.txt $P/r04_sliced_chain_kernel_stats_and_pmc.txt

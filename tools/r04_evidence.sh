@@ -21,4 +21,6 @@ python3 tools/tybench.py --op part --shapes 512x278x512,355x512x355,1024x1024x10
 echo "== notebook 1"; python3 tools/notebook1_bench.py > $O/notebook1.json 2> $O/notebook1.err
 python3 tools/cclbench.py > $O/cclbench.jsonl 2> $O/cclbench.err
 bash tools/nb1prof.sh $TAG > $O/nb1prof.txt 2>&1
+echo "== slab PMC"; bash tools/slab_pmc.sh $TAG > $O/slab_pmc.txt 2>&1; tail -4 $O/slab_pmc.txt | cut -c1-200
+bash tools/slicedprof.sh $TAG --shapes 1024x1024x1024 --intervals 45,5 > $O/slicedprof.txt 2>&1
 echo done
