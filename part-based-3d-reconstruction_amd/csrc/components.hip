@@ -402,6 +402,8 @@ __global__ __launch_bounds__(256) void k_orient128(const u8* __restrict__ grid, 
             }
             w[q] = d;
         }
+        // (round 4 tried six unaligned LDS dword reads -- one per source pixel -- strung together with v_perm instead of the sixteen byte reads:
+        // correct and 45 % SLOWER, 2.04 against 1.41 ms at 1024^3: a misaligned ds_read_b32 a row pitch apart costs more than four byte reads)
         u32x4o r; r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3];
         __builtin_nontemporal_store(r, (u32x4o*)(out + (((z0 + zl) * H + yb) * W + x0) * 3 + 16 * k));
     }

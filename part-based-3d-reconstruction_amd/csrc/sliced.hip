@@ -46,7 +46,20 @@ __global__ __launch_bounds__(256) void k_s32_maskbits(const u8* __restrict__ mas
     if (i >= (i64)G * W) return;
     const i64 g = i / W, x = i - g * W, y0 = 32 * g;
     u32 b = 0;
-    for (int q = 0; q < 32 && y0 + q < H; ++q) b |= (u32)(mask_wh[x * H + y0 + q] != 0) << q;
+    if (y0 + 32 <= H) {
+        // a whole group: its 32 mask bytes are neighbours in memory -- two 16-byte loads at whatever alignment, non-zero bytes gathered into bits
+        // (a loop of 32 dependent byte loads made this 128 KB kernel 8 us long at 1024^2: as much as a tenth of a rotation step)
+        typedef u32 u32x4_m1 __attribute__((ext_vector_type(4), aligned(1)));
+        const u32x4_m1 lo = *(const u32x4_m1*)(mask_wh + x * H + y0), hi = *(const u32x4_m1*)(mask_wh + x * H + y0 + 16);
+        const u32 w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32 t = w[j];
+            const u32 z = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;      // bit 7 of a byte: the byte is non-zero
+            b |= (((z >> 7) * 0x01020408u) >> 24) << (4 * j);
+        }
+    } else
+        for (int q = 0; q < 32 && y0 + q < H; ++q) b |= (u32)(mask_wh[x * H + y0 + q] != 0) << q;
     bits[i] = b;
 }
 
