@@ -110,9 +110,10 @@ int pb3d_rotate_carve(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, i
  * for angle in range(0, 91, angle_interval): rotate-carve; cumulative.  The loop runs on
  * the device.  d_tmp: W*H*D bytes of scratch (ping-pong); d_out may not alias d_occ.
  * Chains of two and more rotation steps (angle_interval <= 45) keep the volume BIT-SLICED between the steps (32 planes per dword,
- * 1/4 B/voxel per middle step instead of 2; csrc/sliced.hip): the first kernel slices and checks that the data is 0 / 1, and the call
- * waits on the host for that one kernel's verdict before it queues the steps (grids with other values take the byte chain, same
- * results).  Everything else about the call is asynchronous on the context's stream, as for the other *_dev entries. */
+ * 1/4 B/voxel per middle step instead of 2; csrc/sliced.hip): the first kernel slices and checks that the data is 0 / 1; the whole chain
+ * is queued behind it and the call then waits on the host for that ONE kernel's verdict (not for the chain): grids with other values
+ * take the byte chain, which overwrites what the queued steps left in d_out -- same results.  Everything else about the call is
+ * asynchronous on the context's stream, as for the other *_dev entries. */
 int pb3d_process_grid_dev(pb3d_ctx* ctx, const uint8_t* d_occ, int64_t W, int64_t H, int64_t D,
                           const uint8_t* d_mask_wh, int angle_interval, uint8_t* d_out, uint8_t* d_tmp);
 int pb3d_process_grid(pb3d_ctx* ctx, const uint8_t* occ, int64_t W, int64_t H, int64_t D,

@@ -693,22 +693,12 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
                 memcpy(sc.p, sp.p, sizeof(sp.p));
                 sc.W = W; sc.D = D; sc.ns = ns; sc.gen = ctx->scratch_gen; sc.valid = nrot_tab <= SMAXSTEPS;
             }
-            if (!checked) {                                            // the slice kernel's verdict (the table build is queued behind it meanwhile)
-                PB3D_HIP(hipEventSynchronize(ctx->s32_ev));
-                checked = true;
-                if (*hflag != 0) return PB3D_EUNSUPPORTED;
-            }
             for (int k = 0; k < ns; ++k) {
                 hipLaunchKernelGGL(k_s32_step, dim3((unsigned)nblk), dim3(STHREADS), 0, ctx->stream, (const u32*)src, dst, (const u32*)mb,
                                    (const STile*)tp + (i64)k * ntiles, W, Dp, G, ntz, ntiles, gpw, nchunks);
                 u32* t2 = src; src = dst; dst = t2;
             }
             PB3D_CHECK_LAUNCH();
-        }
-        if (nrot_tab == 0 && !checked) {                                  // (a chain of ONE fused step: the slice kernel's verdict is still out)
-            PB3D_HIP(hipEventSynchronize(ctx->s32_ev));
-            checked = true;
-            if (*hflag != 0) return PB3D_EUNSUPPORTED;
         }
         if (vbits && d_rgb_hw3) {
             const int utz = (int)((D + UZ - 1) / UZ), utx = (int)((W + UX - 1) / UX);
@@ -724,6 +714,15 @@ static int s32_chain(pb3d_ctx* ctx, const u8* d_occ, i64 W, i64 H, i64 D, const 
         else
             hipLaunchKernelGGL(k_s32_unslice, dim3((total + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)src, d_out, W, H, D, Dp, mzb, mw, total, mg, gfast);
         PB3D_CHECK_LAUNCH();
+        // The slice kernel's verdict on the data (values other than 0 / 1 -> the caller's byte chain) is read AFTER the whole chain has been
+        // queued (round 4; rounds 3 waited for it before the first step: a host round trip in the middle of every chain, with the device
+        // idle).  The wait is for the flag's copy, queued right behind the slice kernel -- not for the chain; on such data the steps already
+        // queued run on garbage into d_out, which the byte chain then overwrites (the input is never written).
+        if (!checked) {
+            PB3D_HIP(hipEventSynchronize(ctx->s32_ev));
+            checked = true;
+            if (*hflag != 0) return PB3D_EUNSUPPORTED;
+        }
         return PB3D_OK;
     };
     rc = body();
