@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_orient_label(const u8* __restrict__ gri
 // source row (fixed x, 128 z) and a destination row (fixed z, 128 x) are both 384 bytes = THREE WHOLE 128-byte lines, moved as 16-byte
 // vectors; the 3-byte pixels are transposed by byte gathers from LDS (row pitch 400 bytes).  k_orient4's 32-pixel tiles cut every row
 // into 96-byte pieces that start mid-line: 0.30 of the HBM peak at Taj 512, 0.39 at 1024^3.
-constexpr int kOT = 128, kOPitch = 400;
+constexpr int kOT = 128, kOPitch = 404;       // 101 dwords: ODD, so the byte gathers of one destination row (pixels a row pitch apart) fall into different banks
 __global__ __launch_bounds__(256) void k_orient128(const u8* __restrict__ grid, u8* __restrict__ out, i64 W, i64 H, i64 D) {
     typedef u32 u32x4o __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) u8 ot[];             // kOT rows of kOPitch bytes
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256) void k_orient128(const u8* __restrict__ grid, 
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         const int i = threadIdx.x + 256 * j, xl = i / 24, k = i - xl * 24;
-        *(u32x4o*)(ot + xl * kOPitch + 16 * k) = v[j];
+        u32* d4 = (u32*)(ot + xl * kOPitch + 16 * k);                     // (dwords: the odd pitch leaves rows 4-byte aligned only)
+        d4[0] = v[j].x; d4[1] = v[j].y; d4[2] = v[j].z; d4[3] = v[j].w;
     }
     __syncthreads();
     const i64 yb = H - 1 - y;
