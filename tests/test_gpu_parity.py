@@ -948,6 +948,37 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_extrude_from_surface_random_shapes(pb3d_gpu, oracle):
+    """extrude_from_surface on seeded grids against the oracle: both axes and directions, widths from 1 to beyond eight 16-plane rounds of
+    the x scan (k_extrude_x, round 4: lanes along z, rounds of doubling length split over eight waves), masks from a few pixels to full
+    (the sparse and the dense regime of the scan), columns that hold nothing, a surface on the very first and the very last plane,
+    depths that run out of the grid, clearing (fill_color None), RGB and label volumes."""
+    rng = np.random.default_rng(909)
+    PC = oracle.PART_COLORS
+    names = list(PC)[:6]
+    lpal = pb3d_gpu.Palette([PC[n] for n in names], names)
+    tab = lpal.table()
+    for (W, H) in [(1, 1), (7, 3), (16, 5), (17, 4), (64, 9), (100, 6), (130, 3), (300, 2), (65, 70)]:
+        D = W                                                              # (axis 0 indexes the (H, W) mask with z: upstream needs D == W)
+        for occ_dens, mask_dens in ((0.02, 0.05), (0.3, 0.5), (0.9, 1.0), (0.0, 0.7)):
+            ids = (rng.integers(1, 7, (W, H, D)) * (rng.random((W, H, D)) < occ_dens)).astype(np.uint8)
+            if W > 2 and occ_dens > 0:
+                ids[0, :, :] = 3; ids[-1, :, 0] = 2; ids[:, :, -1] = 5          # surfaces on the first / last planes of both scans
+                ids[W // 2] *= (rng.random((H, D)) < 0.5)
+            grid = tab[ids]
+            m2 = rng.random((H, W)) < mask_dens
+            for axis in (0, 2):
+                for dirn in ("+", "-"):
+                    for depth, fc in ((1, PC["dome"]), (5, None), (W + 3, PC["plinth"]), (0, PC["dome"])):
+                        want = oracle.extrude_from_surface(grid, m2, axis, direction=dirn, depth=depth, fill_color=None if fc is None else np.array(fc))
+                        got = pb3d_gpu.extrude_from_surface(grid, m2, axis, direction=dirn, depth=depth, fill_color=None if fc is None else np.array(fc))
+                        assert np.array_equal(got, want), (W, H, occ_dens, mask_dens, axis, dirn, depth, fc)
+                        fl = None if fc is None else lpal.label_of([n for n in names if PC[n] == fc][0])
+                        gl = pb3d_gpu.extrude_from_surface_labels(ids, m2, axis=axis, direction=dirn, depth=depth, fill_label=fl)
+                        assert np.array_equal(tab[gl], want), (W, H, occ_dens, mask_dens, axis, dirn, depth, "labels")
+
+
+@pytest.mark.gpu
 def test_global_carve_90_stream_kernel_rgb_and_labels(pb3d_gpu, oracle):
     """global_carve(binary, image, 90) through the stream kernel of round 4 (k_global_carve90s), RGB image and 1-byte label image (row N3),
     against the oracle on widths that are / are not multiples of 16 (groups that straddle two columns, two pixel colours in one group),
