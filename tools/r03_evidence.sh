@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: this script produced the round-3 profiles on the round-3 tree (it uses the numbered misc knobs and kernels that round 4 removed);
+# the current one is tools/r04_evidence.sh.
 # Round-3 evidence, produced on the GPU box in one go from the FINAL tree: the bench line + rocprofv3 kernel stats + PMC traffic of the
 # same command, every op incl. the N2 kernels, the bit-sliced chain (time, per-kernel stats, FETCH / WRITE of a middle step), the
 # global_carve chains, the 256-tile 90-degree kernel against the 128-tile one, the notebook-1 chain (host API, resident, kernel
