@@ -377,6 +377,46 @@ def main():
         ex["process_voxel_grid_angle5_moved_B_per_voxel"] = 2.25 + 0.25 * 18
         for ai in (90, 45):
             ex[f"global_carve_angle{ai}_ms"] = ms_of(lambda: dev.global_carve(d_bhw, d_rgb, S, S, ai, d_full))
+        # ... and the other ops of SURVEY 8(d) that round 4 rebuilt, on the colour grid global_carve(., ., 90) leaves: part_carve with the six
+        # 90-degree jobs of notebook 1 (reference :139-160; ONE launch of k_part90_plane), point extraction of all ten parts (utils/voxel_utils.py:7-21;
+        # count + fill), the notebook's orientation (:384-385) and the labelling of one part colour with its statistics (:175; labels for the
+        # colour's voxels only, what partwise_carve uses).  Never part of `value`; a failure here is recorded, the headline line still leaves.
+        try:
+            import ctypes as C
+            L, lib = pb3d._lib, pb3d._lib.load()
+            d_col = dev.DeviceBuffer(nvox * 3); d_pc = dev.DeviceBuffer(nvox * 3)
+            dev.global_carve(d_bhw, d_rgb, S, S, 90, d_col)
+            rgb_hw = d_rgb.download((S, S, 3))
+            names = ["full_building", "chhatris", "plinth", "front_minarets", "small_minarets", "dome"]
+            msub = np.zeros((len(names), S, S), np.uint8)
+            for j, nm in enumerate(names):
+                msub[j] = np.all(rgb_hw == np.array(pb3d.PART_COLORS[nm], np.uint8), axis=-1).T
+            mcarve = np.ascontiguousarray(msub.transpose(0, 2, 1))          # W == H: upstream's _mask_to_wh transposes a square mask again
+            d_ms = dev.from_numpy(msub); d_mc = dev.from_numpy(mcarve)
+            ang = (C.c_int * 6)(*([90] * 6)); skip = (C.c_int * 6)(*[0 if msub[j].any() else 1 for j in range(6)])
+            ex["part_carve_six_90deg_jobs_ms"] = ms_of(lambda: L.check(lib.pb3d_part_carve_dev(
+                L.ctx(), C.c_void_p(d_col.ptr), S, S, S, C.c_void_p(d_ms.ptr), C.c_void_p(d_mc.ptr), ang, skip, 6, C.c_void_p(d_pc.ptr))))
+            ex["orient_ms"] = ms_of(lambda: L.check(lib.pb3d_orient_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, C.c_void_p(d_pc.ptr))))
+            cols = np.ascontiguousarray(np.array(list(pb3d.PART_COLORS.values()), np.uint8))
+            npt = C.c_int64(0)
+            cnt = lambda: L.check(lib.pb3d_points_count_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), 1, C.byref(npt)))
+            cnt()
+            d_pts = dev.DeviceBuffer(max(1, npt.value) * 12); d_pcl = dev.DeviceBuffer(max(1, npt.value) * 3)
+
+            def extract():
+                cnt()
+                L.check(lib.pb3d_points_fill_dev(L.ctx(), C.c_void_p(d_col.ptr), S, S, S, 3, L.p_u8(cols), len(cols), 1, npt.value,
+                                                 C.c_void_p(d_pts.ptr), C.c_void_p(d_pcl.ptr)))
+            ex["points_by_parts_count_fill_ms"] = ms_of(extract)
+            ex["points_by_parts_points"] = int(npt.value)
+            from pb3d.voxel_carving_utils import _label_stats
+            d_lab = dev.DeviceBuffer(nvox * 4)
+            fb = np.array(pb3d.PART_COLORS["full_building"], np.uint8)
+            ex["label_one_colour_members_only_with_stats_ms"] = ms_of(lambda: _label_stats(d_col, (S, S, S), fb, d_lab, members_only=True))
+            for b in (d_col, d_pc, d_ms, d_mc, d_pts, d_pcl, d_lab):
+                b.free()
+        except Exception as e:  # noqa: BLE001 - extras never take the headline line down
+            ex["extras_error"] = f"{type(e).__name__}: {e}"
         dev.carve_mask(d_in, planes, S, S, 3, d_mslab, d_out)      # d_full holds the carve again (the CPU check below reads it)
         dev.sync()
         out["extras"] = ex
