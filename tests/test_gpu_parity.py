@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT
+from conftest import GOLDEN, PKG, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -945,6 +945,28 @@ def test_part_carve_odd_shapes_w_ne_d(pb3d_gpu, oracle):
                 finally:
                     pb3d_gpu._lib.set_tuning("per_job", 0)
                 assert np.array_equal(got, want), (W, H, D, "job by job", int((got != want).sum()))
+
+
+@pytest.mark.gpu
+def test_named_knobs(pb3d_gpu):
+    """development knobs have names (include/pb3d.h: pb3d_set_tuning): an unknown name and a value out of range are refused with a
+    message that says what the knob takes; PB3D_KNOBS is parsed by pb3d_create (a bad entry fails the creation loudly)."""
+    import subprocess, sys
+    L = pb3d_gpu._lib
+    for name, bad in (("sliced", 2), ("rot90_flat", 3), ("per_job", -1), ("points_fill", 5)):
+        with pytest.raises(ValueError, match=name):
+            L.set_tuning(name, bad)
+        L.set_tuning(name, 0)
+    for name in ("misc0", "misc3", "no_such_knob"):
+        with pytest.raises(ValueError, match="unknown knob"):
+            L.set_tuning(name, 1)
+    code = "import sys; sys.path.insert(0, %r); import pb3d; pb3d._lib.ctx(); print('created')" % PKG
+    env = dict(os.environ, PB3D_KNOBS="sliced=1,per_job=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "created" in r.stdout, r.stderr[-400:]
+    env = dict(os.environ, PB3D_KNOBS="sliced=1,bogus=3")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "unknown knob" in (r.stderr + r.stdout), (r.returncode, r.stderr[-400:])
 
 
 @pytest.mark.gpu
