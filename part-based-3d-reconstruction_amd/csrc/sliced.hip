@@ -24,7 +24,14 @@ typedef u32x2 u32x2_a1 __attribute__((aligned(1)));     // 8-byte access at any 
 constexpr int ST = 64;              // output tile edge (x and z)
 constexpr int STHREADS = 256;       // 16 cells per thread: 4 consecutive z in each of 4 rows
 constexpr int SROWS = 96;           // footprint rows in LDS (a rotated 64-tile spans <= 64 sqrt 2 + 2 = 92.6)
-constexpr int SPITCH = 97;          // LDS row pitch in dwords: ODD, so the 4 rows x 16 column groups a wave reads together hit 64 banks
+// LDS row pitch in dwords: ODD, so the 4 rows x 16 column groups a wave reads together hit 64 banks at 0 and 90 degrees.  At the angles in
+// between the taps of a wave walk the footprint diagonally and WHICH odd pitch matters: 97 / 99 / 101 / 103 interleaved on one box at 1024^3
+// (tools/slicedbench.py, builds with -DPB3D_SPITCH=...): 18 sweeps 1.72 / 1.66 / 1.63 / 1.69 ms, the 45-degree chain 0.586 / 0.540 / 0.535 /
+// 0.551 -- 101 it is (96 x 101 dwords = 38.8 KB: still four workgroups per CU; 105 would leave three).
+#ifndef PB3D_SPITCH
+#define PB3D_SPITCH 101
+#endif
+constexpr int SPITCH = PB3D_SPITCH;
 constexpr int SMAXU = 9;            // 16-byte units per thread: a full bounding box of 95 rows x 24 units
 constexpr int SMAXSTEPS = 32;       // steps per table build
 
